@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container, where /root/reference exists; the .npz files it
+writes are committed and are what travels to the GPU box.  Inputs are produced by
+the build's own deterministic generators (torch_nerf.amd.synth); outputs are
+whatever the reference's CPU path (torch 2.10.0 CPU) returns for them.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixture plan = SURVEY.md section 8(c) F1..F7.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = os.environ.get("NERF_REFERENCE", "/root/reference")
+
+# the build's generators (numpy only) -- loaded by file path so that the build's own
+# `torch_nerf` package does not shadow the reference's `torch_nerf`
+import importlib.util
+
+_spec = importlib.util.spec_from_file_location(
+    "nerf_synth", os.path.join(ROOT, "torch-nerf_amd", "torch_nerf", "amd", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
+
+sys.path.insert(0, REFERENCE)
+import torch_nerf.src.renderer.cameras as ref_cameras  # noqa: E402
+import torch_nerf.src.renderer.integrators.quadrature_integrator as ref_integrators  # noqa: E402
+import torch_nerf.src.renderer.ray_samplers as ref_samplers  # noqa: E402
+import torch_nerf.src.renderer.volume_renderer as ref_vr  # noqa: E402
+import torch_nerf.src.network.nerf as ref_nerf  # noqa: E402
+import torch_nerf.src.scene as ref_scene  # noqa: E402
+from torch_nerf.src.renderer.ray_samplers.utils import sample_pdf as ref_sample_pdf  # noqa: E402
+from torch_nerf.src.signal_encoder.positional_encoder import PositionalEncoder as RefPE  # noqa: E402
+
+assert ref_vr.__file__.startswith(REFERENCE), ref_vr.__file__
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def load_ref_net(flat):
+    net = ref_nerf.NeRF(63, 27)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.split_flat_params(flat).items()}
+    net.load_state_dict(sd)
+    return net
+
+
+def camera(H, W, focal, pose, near, far):
+    return ref_cameras.PerspectiveCamera(
+        {"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
+        torch.from_numpy(np.asarray(pose, np.float32).copy()), near, far)
+
+
+# ---------------------------------------------------------------- F1 raygen
+def f1_raygen():
+    out = {}
+    sampler = ref_samplers.StratifiedSampler()
+    integ = ref_integrators.QuadratureIntegrator()
+    cases = [
+        ("blender", 800, 800, float(synth.blender_focal(800)), synth.pose_spherical(37.0, -30.0, 4.0),
+         2.0, 6.0, False),
+        ("blender400", 400, 400, float(synth.blender_focal(400)),
+         synth.pose_spherical(-153.0, -30.0, 4.0), 2.0, 6.0, False),
+        ("llff_ndc0", 756, 1008, 815.0, synth.llff_like_pose(), 0.0, 1.0, True),
+        ("llff_ndc1", 756, 1008, 815.0, synth.llff_like_pose(), 1.0, 1.0 + 1.0, True),
+    ]
+    for name, H, W, focal, pose, near, far, ndc in cases:
+        cam = camera(H, W, focal, pose, near, far)
+        vr = ref_vr.VolumeRenderer(integ, sampler, cam)
+        corners = np.array([0, W - 1, (H - 1) * W, H * W - 1, (H // 2) * W + W // 2], np.int64)
+        pix = np.concatenate([corners, synth.pixel_batch(11, H, W, 251)])
+        coords = vr.screen_coords.clone()[torch.from_numpy(pix), :]
+        bundle = sampler.generate_rays(coords, cam, project_to_ndc=ndc)
+        out[name + "_meta"] = np.array([H, W, focal, near, far, float(ndc)], np.float64)
+        out[name + "_pose"] = np.asarray(pose, np.float32)
+        out[name + "_pix"] = pix
+        out[name + "_coords"] = coords.numpy()
+        out[name + "_o"] = bundle.ray_origin.numpy()
+        out[name + "_d"] = bundle.ray_dir.numpy()
+        out[name + "_intrinsic"] = cam.intrinsic.numpy()
+    # full screen-coordinate table checksum for one small camera
+    cam = camera(6, 5, 10.0, synth.pose_spherical(0.0, -30.0, 4.0), 2.0, 6.0)
+    vr = ref_vr.VolumeRenderer(integ, sampler, cam)
+    out["small_coords_6x5"] = vr.screen_coords.numpy()
+    # analytic pose generator parity (load_blender.pose_spherical needs imageio: optional)
+    save("f1_raygen", **out)
+
+
+def rays_for(n, seed):
+    """Blender rays from a seeded pixel batch via the reference."""
+    H = W = 800
+    cam = camera(H, W, float(synth.blender_focal(W)), synth.pose_spherical(37.0, -30.0, 4.0), 2.0, 6.0)
+    sampler = ref_samplers.StratifiedSampler()
+    vr = ref_vr.VolumeRenderer(ref_integrators.QuadratureIntegrator(), sampler, cam)
+    pix = synth.pixel_batch(seed, H, W, n)
+    bundle = sampler.generate_rays(vr.screen_coords.clone()[torch.from_numpy(pix), :], cam, False)
+    return cam, vr, pix, bundle
+
+
+# ---------------------------------------------------------------- F2 coarse sampling
+def f2_coarse():
+    out = {}
+    sampler = ref_samplers.StratifiedSampler()
+    for name, near, far, S in (("b", 2.0, 6.0, 64), ("ndc", 0.0, 1.0, 64), ("odd", 0.5, 3.25, 40)):
+        _, _, _, bundle = rays_for(48, 5)
+        bundle = ref_samplers.RayBundle(bundle.ray_origin, bundle.ray_dir, near, far, False)
+        torch.manual_seed(1234)
+        u1 = torch.rand((48, S))
+        torch.manual_seed(1234)
+        pts, dirs, delta = sampler.sample_along_rays(bundle, S, device="cpu")
+        t_bins, ps = sampler._create_t_bins(near, far, S, "cpu")
+        out[name + "_meta"] = np.array([near, far, S], np.float64)
+        out[name + "_o"] = bundle.ray_origin.numpy()
+        out[name + "_d"] = bundle.ray_dir.numpy()
+        out[name + "_u1"] = u1.numpy()
+        out[name + "_t_bins"] = t_bins.numpy()
+        out[name + "_ps"] = np.array([ps], np.float64)
+        out[name + "_pts"] = pts.numpy()
+        out[name + "_dirs"] = dirs.numpy()
+        out[name + "_delta"] = delta.numpy()
+    save("f2_coarse", **out)
+
+
+# ---------------------------------------------------------------- F3 fine sampling
+def adversarial_weights(n, S, seed):
+    rng = np.random.RandomState(seed)
+    w = rng.rand(n, S).astype(np.float32)
+    w[0] = 0.0                                   # all-zero row -> uniform pdf from the 1e-5 floor
+    w[1] = 0.0; w[1, 17 % S] = 1.0               # one-hot
+    w[2] = 0.0; w[2, S - 1] = 1.0                # all mass in the last bin
+    w[3] = 0.0; w[3, 0] = 1.0                    # all mass in the first bin
+    w[4] = (10.0 ** rng.uniform(-12, 0, S)).astype(np.float32)   # huge dynamic range
+    w[5] = 1e-12                                 # far below the floor
+    w[6] = np.float32(1.0)                       # exactly uniform
+    w[7] = np.exp(-0.5 * ((np.arange(S) - S / 2) / 2.0) ** 2).astype(np.float32)  # a narrow peak
+    w[8:16] = (rng.rand(8, S) ** 8).astype(np.float32)
+    # rows 16.. look like real compositing weights: T*alpha with decaying transmittance
+    sig = rng.gamma(0.5, 4.0, size=(n - 16, S)).astype(np.float32)
+    tau = sig * np.float32(4.0 / S)
+    T = np.exp(-np.concatenate([np.zeros((n - 16, 1), np.float32), np.cumsum(tau, 1)[:, :-1]], 1))
+    w[16:] = (T * (1 - np.exp(-tau))).astype(np.float32)
+    return w
+
+
+def f3_fine():
+    out = {}
+    sampler = ref_samplers.StratifiedSampler()
+    for name, near, far, Sc, Sf, n in (("b", 2.0, 6.0, 64, 128, 96), ("ndc", 0.0, 1.0, 64, 128, 32),
+                                       ("s128", 2.0, 6.0, 128, 64, 32), ("s40", 2.0, 6.0, 40, 24, 32),
+                                       ("s1000", 2.0, 6.0, 1000, 16, 24)):
+        _, _, _, bundle = rays_for(n, 7)
+        bundle = ref_samplers.RayBundle(bundle.ray_origin, bundle.ray_dir, near, far, False)
+        w_in = adversarial_weights(n, Sc, 99)
+        torch.manual_seed(4321)
+        u1 = torch.rand((n, Sc)); u2 = torch.rand((n, Sf)); u3 = torch.rand((n, Sf))
+        # (a) the whole branch through the public API
+        w_t = torch.from_numpy(w_in.copy())
+        torch.manual_seed(4321)
+        pts, dirs, delta = sampler.sample_along_rays(bundle, (Sc, Sf), device="cpu", weights=w_t)
+        # (b) the bin indices, by replaying sample_pdf's arithmetic with ATen ops on the same draws
+        t_bins, ps = sampler._create_t_bins(near, far, Sc, "cpu")
+        w2 = torch.from_numpy(w_in.copy())
+        w2 += 1e-5
+        pdf = w2 / torch.sum(w2, dim=-1, keepdim=True)
+        cdf = torch.cumsum(pdf, dim=-1)
+        cdf = torch.cat([torch.zeros((n, 1)), cdf[..., :-1]], dim=-1)
+        idx = torch.searchsorted(cdf, u2.contiguous(), right=True) - 1
+        t_f = torch.gather(t_bins.unsqueeze(0).repeat(n, 1), 1, idx) + ps * u3
+        t_c = t_bins.unsqueeze(0).repeat(n, 1) + ps * u1
+        t_sorted, _ = torch.sort(torch.cat([t_c, t_f], -1), -1)
+        # the replay must reproduce the API call bit for bit, or the replay is wrong
+        d_chk = torch.diff(torch.cat([t_sorted, 1e8 * torch.ones((n, 1))], -1), n=1, dim=-1)
+        assert torch.equal(d_chk, delta), "replayed draws do not match the reference API call"
+        assert torch.equal(w2, w_t), "in-place weight floor mismatch"
+        out[name + "_meta"] = np.array([near, far, Sc, Sf], np.float64)
+        out[name + "_o"] = bundle.ray_origin.numpy(); out[name + "_d"] = bundle.ray_dir.numpy()
+        out[name + "_w_in"] = w_in; out[name + "_w_after"] = w_t.numpy()
+        out[name + "_u1"] = u1.numpy(); out[name + "_u2"] = u2.numpy(); out[name + "_u3"] = u3.numpy()
+        out[name + "_t_bins"] = t_bins.numpy(); out[name + "_ps"] = np.array([ps], np.float64)
+        out[name + "_norm"] = torch.sum(w2, dim=-1).numpy()
+        out[name + "_idx"] = idx.numpy().astype(np.int16)
+        out[name + "_t"] = t_sorted.numpy()
+        out[name + "_delta"] = delta.numpy()
+        out[name + "_pts"] = pts.numpy()
+    save("f3_fine", **out)
+
+
+# ---------------------------------------------------------------- F4 positional encoding
+def f4_posenc():
+    rng = np.random.RandomState(3)
+    x = np.concatenate([rng.uniform(-6, 6, (192, 3)), rng.uniform(-1.5, 1.5, (60, 3)),
+                        np.array([[0.0, -0.0, 1.0], [6.0, -6.0, 3.14159265], [1e-8, 100.0, -250.0],
+                                  [0.5, 0.25, -0.125]])]).astype(np.float32)
+    pe10 = RefPE(3, 10, True).encode(torch.from_numpy(x)).numpy()
+    pe4 = RefPE(3, 4, True).encode(torch.from_numpy(x)).numpy()
+    pe4n = RefPE(3, 4, False).encode(torch.from_numpy(x)).numpy()
+    save("f4_posenc", x=x, pe10=pe10, pe4=pe4, pe4_noinput=pe4n)
+
+
+GRAD_SLICE = 192
+
+
+def grad_digest(net):
+    """Per-tensor norm + sum + leading slice + strided sample of the parameter grads."""
+    d = {}
+    for k, p in net.named_parameters():
+        g = p.grad.detach().reshape(-1).numpy()
+        d[k + ".norm"] = np.array([np.sqrt(np.sum(g.astype(np.float64) ** 2))])
+        d[k + ".sum"] = np.array([np.sum(g.astype(np.float64))])
+        d[k + ".head"] = g[:GRAD_SLICE].copy()
+        d[k + ".stride"] = g[:: max(1, g.size // GRAD_SLICE)][:GRAD_SLICE].copy()
+    return d
+
+
+# ---------------------------------------------------------------- F5 MLP
+def f5_mlp():
+    rng = np.random.RandomState(17)
+    M = 256
+    pts = rng.uniform(-4, 4, (M, 3)).astype(np.float32)
+    dirs = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    out = dict(pts=pts, dirs=dirs)
+    pe = RefPE(3, 10, True).encode(torch.from_numpy(pts))
+    de = RefPE(3, 4, True).encode(torch.from_numpy(dirs))
+    for tag, kw in (("default", dict(seed=1)), ("dense", dict(seed=2, sigma_bias=1.0, sigma_gain=30.0))):
+        flat = synth.nerf_flat_params(**kw)
+        net = load_ref_net(flat)
+        sigma, rgb = net(pe, de)
+        g_sigma = torch.from_numpy(rng.standard_normal(M).astype(np.float32))
+        g_rgb = torch.from_numpy(rng.standard_normal((M, 3)).astype(np.float32))
+        (sigma * g_sigma).sum().add((rgb * g_rgb).sum()).backward()
+        out[tag + "_sigma"] = sigma.detach().numpy(); out[tag + "_rgb"] = rgb.detach().numpy()
+        out[tag + "_g_sigma"] = g_sigma.numpy(); out[tag + "_g_rgb"] = g_rgb.numpy()
+        for k, v in grad_digest(net).items():
+            out[tag + "_grad_" + k] = v
+    save("f5_mlp", **out)
+
+
+# ---------------------------------------------------------------- F6 compositing
+def f6_composite():
+    out = {}
+    rng = np.random.RandomState(23)
+    integ = ref_integrators.QuadratureIntegrator()
+    for S in (64, 192, 7):
+        n = 40
+        sigma = rng.gamma(0.7, 3.0, (n, S)).astype(np.float32)
+        sigma[0] = 0.0
+        sigma[1] = 1e3
+        sigma[2, ::2] = 0.0
+        sigma[3] = 1e-6
+        c = rng.rand(n, S, 3).astype(np.float32)
+        t = np.sort(rng.uniform(2, 6, (n, S)).astype(np.float32), axis=1)
+        delta = np.diff(np.concatenate([t, np.full((n, 1), 1e8, np.float32)], 1), axis=1).astype(np.float32)
+        g_rgb = rng.standard_normal((n, 3)).astype(np.float32)
+        g_w = rng.standard_normal((n, S)).astype(np.float32)
+        st = torch.from_numpy(sigma).requires_grad_(True)
+        ct = torch.from_numpy(c).requires_grad_(True)
+        rgb, w = integ.integrate_along_rays(st, ct, torch.from_numpy(delta))
+        (rgb * torch.from_numpy(g_rgb)).sum().backward()
+        gs1, gc1 = st.grad.clone(), ct.grad.clone()
+        st.grad = None; ct.grad = None
+        rgb2, w2 = integ.integrate_along_rays(st, ct, torch.from_numpy(delta))
+        ((rgb2 * torch.from_numpy(g_rgb)).sum() + (w2 * torch.from_numpy(g_w)).sum()).backward()
+        p = f"S{S}_"
+        out.update({p + "sigma": sigma, p + "c": c, p + "delta": delta, p + "g_rgb": g_rgb,
+                    p + "g_w": g_w, p + "rgb": rgb.detach().numpy(), p + "w": w.detach().numpy(),
+                    p + "gs": gs1.numpy(), p + "gc": gc1.numpy(), p + "gs_w": st.grad.numpy(),
+                    p + "gc_w": ct.grad.numpy()})
+    save("f6_composite", **out)
+
+
+# ---------------------------------------------------------------- F7 end to end
+def f7_e2e():
+    out = {}
+    n = 96
+    cam, vr, pix, _ = rays_for(n, 31)
+    flat_c = synth.nerf_flat_params(seed=3, sigma_bias=1.0, sigma_gain=30.0)
+    flat_f = synth.nerf_flat_params(seed=4, sigma_bias=1.0, sigma_gain=30.0)
+    enc = {"coord_enc": RefPE(3, 10, True), "dir_enc": RefPE(3, 4, True)}
+    net_c, net_f = load_ref_net(flat_c), load_ref_net(flat_f)
+    scene_c = ref_scene.PrimitiveCube(net_c, enc)
+    scene_f = ref_scene.PrimitiveCube(net_f, enc)
+    gt = synth.counter_uniform(77, 0, n * 3).reshape(n, 3)
+    # the draws the two passes will consume, in order (coarse: U1c ; fine: U1, U2, U3)
+    torch.manual_seed(2024)
+    u1c = torch.rand((n, 64)); u1 = torch.rand((n, 64)); u2 = torch.rand((n, 128)); u3 = torch.rand((n, 128))
+    torch.manual_seed(2024)
+    pix_t = torch.from_numpy(pix)
+    c_rgb, c_idx, c_w = vr.render_scene(scene_c, n, 64, False, "cpu", pixel_indices=pix_t)
+    c_w_before = c_w.detach().clone()
+    f_rgb, f_idx, f_w = vr.render_scene(scene_f, n, (64, 128), False, "cpu", pixel_indices=c_idx,
+                                        weights=c_w)
+    mse = torch.nn.MSELoss()
+    loss = mse(torch.from_numpy(gt), c_rgb) + mse(torch.from_numpy(gt), f_rgb)
+    loss.backward()
+    out.update(dict(pix=pix, pose=cam.extrinsic.numpy(), meta=np.array([800, 800, cam.focal_lengths[0], 2.0, 6.0]),
+                    gt=gt, u1c=u1c.numpy(), u1=u1.numpy(), u2=u2.numpy(), u3=u3.numpy(),
+                    coarse_rgb=c_rgb.detach().numpy(), coarse_w=c_w_before.numpy(),
+                    coarse_w_after=c_w.detach().numpy(), fine_rgb=f_rgb.detach().numpy(),
+                    fine_w=f_w.detach().numpy(), loss=np.array([loss.item()]),
+                    idx_match=np.array([int(torch.equal(c_idx, pix_t) and torch.equal(f_idx, pix_t))])))
+    for tag, net in (("coarse", net_c), ("fine", net_f)):
+        for k, v in grad_digest(net).items():
+            out[tag + "_grad_" + k] = v
+    save("f7_e2e", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    f1_raygen(); f2_coarse(); f3_fine(); f4_posenc(); f5_mlp(); f6_composite(); f7_e2e()

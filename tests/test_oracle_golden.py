@@ -1,0 +1,145 @@
+"""The CPU oracle against the golden vectors captured from the imported reference.
+
+This is what pins the oracle: integer quantities (screen
+coordinates, fine-sample bin indices) and everything built only from IEEE +,-,*,/
+must match the reference bit for bit; transcendental / GEMM-order quantities match
+to the tolerances written next to each assert.
+"""
+import numpy as np
+import pytest
+
+from torch_nerf.amd import synth
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_screen_coords_and_rays(golden, oracle):
+    g = golden("f1_raygen")
+    assert np.array_equal(oracle.screen_coords(6, 5), g["small_coords_6x5"])
+    for name in ("blender", "blender400", "llff_ndc0", "llff_ndc1"):
+        H, W, focal, near, far, ndc = g[name + "_meta"]
+        H, W = int(H), int(W)
+        pix = g[name + "_pix"]
+        coords = oracle.screen_coords(H, W, pix)
+        assert np.array_equal(coords, g[name + "_coords"]), name
+        K = g[name + "_intrinsic"]
+        o, d = oracle.raygen(coords, K[0, 0], K[1, 1], K[0, 2], K[1, 2], g[name + "_pose"])
+        if ndc:
+            o, d = oracle.map_rays_to_ndc(float(focal), float(near), H, W, o, d)
+        # sgemm order / FMA use inside ATen's (N,3)@(3,3) is not restated: 2 ulp-ish
+        np.testing.assert_allclose(o, g[name + "_o"], rtol=3e-6, atol=1e-6, err_msg=name)
+        np.testing.assert_allclose(d, g[name + "_d"], rtol=3e-6, atol=1e-6, err_msg=name)
+
+
+def test_pose_generator_matches_fixture_pose(golden):
+    g = golden("f1_raygen")
+    assert np.array_equal(synth.pose_spherical(37.0, -30.0, 4.0), g["blender_pose"])
+
+
+@pytest.mark.parametrize("name", ["b", "ndc", "odd"])
+def test_coarse_sampling_bit_exact(golden, oracle, name):
+    g = golden("f2_coarse")
+    t, pts, dirs, delta = oracle.stratified_sample(g[name + "_o"], g[name + "_d"], g[name + "_t_bins"],
+                                                   float(g[name + "_ps"][0]), g[name + "_u1"])
+    assert np.array_equal(_bits(delta), _bits(g[name + "_delta"]))
+    assert np.array_equal(_bits(pts), _bits(g[name + "_pts"]))
+    assert np.array_equal(_bits(dirs), _bits(g[name + "_dirs"]))
+
+
+@pytest.mark.parametrize("name", ["b", "ndc", "s128", "s40", "s1000"])
+def test_fine_sampling_bit_exact(golden, oracle, name):
+    g = golden("f3_fine")
+    # ATen's sum order, restated
+    w_after = g[name + "_w_after"]
+    norm = np.array([oracle.aten_sum_lastdim(r) for r in w_after], np.float32)
+    assert np.array_equal(_bits(norm), _bits(g[name + "_norm"])), "sum order"
+    idx, t, pts, dirs, delta, w = oracle.hierarchical_sample(
+        g[name + "_o"], g[name + "_d"], g[name + "_t_bins"], float(g[name + "_ps"][0]),
+        g[name + "_w_in"], g[name + "_u1"], g[name + "_u2"], g[name + "_u3"])
+    assert np.array_equal(_bits(w), _bits(w_after)), "in-place floor"
+    assert np.array_equal(idx, g[name + "_idx"].astype(np.int64)), "bin indices"
+    assert np.array_equal(_bits(t), _bits(g[name + "_t"])), "sorted t"
+    assert np.array_equal(_bits(delta), _bits(g[name + "_delta"]))
+    assert np.array_equal(_bits(pts), _bits(g[name + "_pts"]))
+
+
+def test_posenc(golden, oracle):
+    g = golden("f4_posenc")
+    x = g["x"]
+    # glibc sinf/cosf vs ATen's SLEEF: <= 2 ulp of values in [-1,1]
+    np.testing.assert_allclose(oracle.posenc(x, 10), g["pe10"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(oracle.posenc(x, 4), g["pe4"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(oracle.posenc(x, 4, include_input=False), g["pe4_noinput"], rtol=0, atol=3e-7)
+    # layout: raw input first, then per-frequency [sin(xyz), cos(xyz)]
+    assert np.array_equal(oracle.posenc(x, 10)[:, :3], x)
+
+
+GRAD_KW = {"default": dict(seed=1), "dense": dict(seed=2, sigma_bias=1.0, sigma_gain=30.0)}
+
+
+def _check_grad_digest(flat_grad, g, prefix, rtol, atol_scale):
+    grads = synth.split_flat_params(flat_grad)
+    for k, v in grads.items():
+        v = v.reshape(-1)
+        norm_ref = float(g[prefix + k + ".norm"][0])
+        atol = atol_scale * max(norm_ref / np.sqrt(v.size), 1e-12)
+        head = g[prefix + k + ".head"]
+        strided = g[prefix + k + ".stride"]
+        np.testing.assert_allclose(v[:head.size], head, rtol=rtol, atol=atol, err_msg=k)
+        step = max(1, v.size // 192)
+        np.testing.assert_allclose(v[::step][:strided.size], strided, rtol=rtol, atol=atol, err_msg=k)
+        norm = np.sqrt(np.sum(v.astype(np.float64) ** 2))
+        assert abs(norm - norm_ref) <= 1e-4 * norm_ref + 1e-12, k
+
+
+@pytest.mark.parametrize("tag", ["default", "dense"])
+def test_mlp_forward_backward(golden, oracle, tag):
+    g = golden("f5_mlp")
+    flat = synth.nerf_flat_params(**GRAD_KW[tag])
+    pe = oracle.posenc(g["pts"], 10)
+    de = oracle.posenc(g["dirs"], 4)
+    sigma, rgb = oracle.mlp_forward(flat, pe, de)
+    # north-star tolerance: 1e-5 abs on sigma / rgb
+    np.testing.assert_allclose(sigma, g[tag + "_sigma"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(rgb, g[tag + "_rgb"], rtol=0, atol=1e-5)
+    grad = oracle.mlp_backward(flat, pe, de, g[tag + "_g_sigma"], g[tag + "_g_rgb"])
+    _check_grad_digest(grad, g, tag + "_grad_", rtol=2e-4, atol_scale=2e-3)
+
+
+@pytest.mark.parametrize("S", [64, 192, 7])
+def test_composite(golden, oracle, S):
+    g = golden("f6_composite")
+    p = f"S{S}_"
+    rgb, w = oracle.composite_forward(g[p + "sigma"], g[p + "c"], g[p + "delta"])
+    np.testing.assert_allclose(w, g[p + "w"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rgb, g[p + "rgb"], rtol=0, atol=1e-5)
+    gs, gc = oracle.composite_backward(g[p + "sigma"], g[p + "c"], g[p + "delta"], g[p + "g_rgb"])
+    np.testing.assert_allclose(gc, g[p + "gc"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gs, g[p + "gs"], rtol=1e-4, atol=1e-4)
+    gs, gc = oracle.composite_backward(g[p + "sigma"], g[p + "c"], g[p + "delta"], g[p + "g_rgb"],
+                                       g[p + "g_w"])
+    np.testing.assert_allclose(gc, g[p + "gc_w"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gs, g[p + "gs_w"], rtol=1e-4, atol=1e-4)
+
+
+def test_end_to_end(golden, oracle):
+    g = golden("f7_e2e")
+    H, W, focal, near, far = g["meta"]
+    H, W = int(H), int(W)
+    assert int(g["idx_match"][0]) == 1
+    coords = oracle.screen_coords(H, W, g["pix"])
+    o, d = oracle.raygen(coords, np.float32(focal), np.float32(focal), W / 2.0, H / 2.0, g["pose"])
+    import torch
+    t_bins = torch.linspace(float(near), float(far), 65)[:-1].numpy()
+    ps = (float(far) - float(near)) / 64
+    pc = synth.nerf_flat_params(seed=3, sigma_bias=1.0, sigma_gain=30.0)
+    pf = synth.nerf_flat_params(seed=4, sigma_bias=1.0, sigma_gain=30.0)
+    c = oracle.render_rays(pc, o, d, t_bins, ps, g["u1c"])
+    np.testing.assert_allclose(c["rgb"], g["coarse_rgb"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(c["weights"], g["coarse_w"], rtol=0, atol=1e-5)
+    # fine pass driven by the REFERENCE's coarse weights so that bins are comparable bit for bit
+    f = oracle.render_rays(pf, o, d, t_bins, ps, g["u1"], weights=g["coarse_w"], u2=g["u2"], u3=g["u3"])
+    np.testing.assert_allclose(f["rgb"], g["fine_rgb"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(f["weights"], g["fine_w"], rtol=0, atol=1e-5)
