@@ -1,0 +1,144 @@
+/*
+ * nerf_amd.h -- C ABI of libnerf_amd.so, the MI355X (gfx950) volume-rendering path.
+ *
+ * The reference (DveloperY0115/torch-NeRF) is pure Python/PyTorch: it has NO FFI,
+ * plugin or operator interface of its own.  The boundary a
+ * maintainer binds is therefore the Python class surface of torch_nerf/src/...,
+ * and this header is the native layer directly beneath it: one entry point per
+ * reference function on the hot path, each citing the function it replaces
+ * (R/ = /root/reference/torch_nerf/src/).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *    buffers are owned by the caller and must outlive the call; no ownership moves
+ *  - all tensors are dense, row-major, fp32 unless typed otherwise
+ *  - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised
+ *  - return value: 0 = NERF_OK, otherwise an error code; nothing throws;
+ *    nerf_amd_last_error() returns a thread-local message for the last failure
+ *  - re-entrant; no global mutable state
+ *  - IEEE fp32 with separately rounded multiply/add wherever the reference's
+ *    result decides an integer (sample bins) -- see DESIGN.md "numerics"
+ */
+#ifndef NERF_AMD_H
+#define NERF_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_AMD_ABI_VERSION 1
+
+enum {
+    NERF_OK = 0,
+    NERF_ERR_ARG = 1,         /* null pointer / size out of range                */
+    NERF_ERR_UNSUPPORTED = 2, /* configuration outside what the kernels support  */
+    NERF_ERR_LAUNCH = 3       /* the HIP runtime rejected a launch               */
+};
+
+typedef void *nerf_stream_t; /* hipStream_t */
+
+int nerf_amd_abi_version(void);
+const char *nerf_amd_last_error(void);
+
+/* ---- a2: VolumeRenderer._generate_screen_coords, R/renderer/volume_renderer.py:171-190
+ * coords[i] = (p % W, (H-1) - p / W) with p = pix ? pix[i] : first + i.  int64 (n,2). */
+int nerf_screen_coords(int64_t H, int64_t W, const int64_t *pix, int64_t first, int64_t n,
+                       int64_t *coords, nerf_stream_t stream);
+
+/* ---- a4 + a5: RaySamplerBase.generate_rays / _get_ray_directions / map_rays_to_ndc,
+ * R/renderer/ray_samplers/sampler_base.py:70-113, :134-197, :199-257
+ * Pixel source, first non-null wins: `coords` int64 (n,2) | `pix` int64 (n,) | first+i.
+ * intrinsic = (fx, fy, cx, cy) read from the 4x4 matrix; extrinsic_host = 12 floats,
+ * the row-major [R|t] 3x4 block of the camera-to-world matrix (HOST memory).
+ * project_to_ndc != 0 applies map_rays_to_ndc(focal, z_near, H, W). */
+int nerf_generate_rays(const int64_t *coords, const int64_t *pix, int64_t first, int64_t n,
+                       int64_t H, int64_t W, float fx, float fy, float cx, float cy,
+                       const float *extrinsic_host, int project_to_ndc, double focal,
+                       double z_near, float *ray_o, float *ray_d, nerf_stream_t stream);
+
+/* ---- a6: StratifiedSampler.sample_along_rays (coarse branch) + _create_t_bins,
+ * R/renderer/ray_samplers/stratified_sampler.py:91-128, :130-164
+ * t = t_bins + ps*u1 ; delta = diff(cat[t,1e8]) ; pts = o + t*d ; dirs = d.
+ * t_bins (S,) is torch.linspace(t_near,t_far,S+1)[:-1] made by the caller;
+ * u1 (n,S) are the caller's torch.rand_like draws.  `t` (n,S) may be NULL. */
+int nerf_sample_stratified(const float *ray_o, const float *ray_d, int64_t n, int S,
+                           const float *t_bins, float partition_size, const float *u1, float *t,
+                           float *pts, float *dirs, float *delta, nerf_stream_t stream);
+
+/* ---- a7: hierarchical branch + sample_pdf,
+ * R/renderer/ray_samplers/stratified_sampler.py:57-90, R/renderer/ray_samplers/utils.py:8-58
+ * weights (n,Sc) is MUTATED in place (+= 1e-5, utils.py:31).  u1 (n,Sc), u2 (n,Sf),
+ * u3 (n,Sf) are the three draws in the reference's order.  Outputs have S = Sc+Sf
+ * samples per ray, sorted.  `bin_idx` int64 (n,Sf) and `t` (n,S) may be NULL.
+ * Bin indices are bit-exact with the reference's CPU path (ATen sum / cumsum order). */
+int nerf_sample_hierarchical(const float *ray_o, const float *ray_d, int64_t n, int Sc, int Sf,
+                             const float *t_bins, float partition_size, float *weights,
+                             const float *u1, const float *u2, const float *u3, int64_t *bin_idx,
+                             float *t, float *pts, float *dirs, float *delta,
+                             nerf_stream_t stream);
+
+/* ---- a8: PositionalEncoder.encode, R/signal_encoder/positional_encoder.py:49-104
+ * x (M,C) -> out (M, 2*L*C + (include_input ? C : 0)). */
+int nerf_posenc(const float *x, int64_t M, int C, int L, int include_input, float *out,
+                nerf_stream_t stream);
+
+/* ---- a10: NeRF (11 Linear layers), R/network/nerf.py:24-63, :65-121
+ * Fixed architecture: pos_dim 63 (L=10), view_dir_dim 27 (L=4), feat_dim 256.
+ * `params` is the flat state_dict blob: fc_in.weight (256,63), fc_in.bias, fc_1.weight,
+ * ... fc_out.weight (3,128), fc_out.bias = nerf_mlp_param_count() floats.
+ * nerf_mlp_pack re-tiles it into the LDS image the kernels stream
+ * (nerf_mlp_packed_bytes() bytes); re-run after every parameter update. */
+int64_t nerf_mlp_param_count(void);
+int64_t nerf_mlp_packed_bytes(void);
+int nerf_mlp_pack(const float *params, void *packed, nerf_stream_t stream);
+
+/* Forward of PrimitiveCube.query_points (R/scene/primitives/cube.py:39-76) fused with
+ * both PositionalEncoder.encode calls and NeRF.forward:
+ *   encoded == 0: pos (M,3), view_dir (M,3) raw; encoding happens in registers
+ *   encoded != 0: pos (M,63), view_dir (M,27) already encoded (plain NeRF.forward)
+ * sigma (M,), rgb (M,3).  `saved` = NULL for inference, or nerf_mlp_saved_bytes(M)
+ * bytes that receive the activation record nerf_mlp_backward needs. */
+int64_t nerf_mlp_saved_bytes(int64_t M);
+int nerf_mlp_forward(const void *packed, const float *pos, const float *view_dir, int64_t M,
+                     int encoded, float *sigma, float *rgb, void *saved, nerf_stream_t stream);
+
+/* ---- a13 (MLP part): gradients of all 22 parameter tensors (autograd in the
+ * reference, entered at runners/train.py:215).  g_params (param_count floats, same
+ * layout as `params`) is OVERWRITTEN.  workspace: nerf_mlp_backward_workspace_bytes(M). */
+int64_t nerf_mlp_backward_workspace_bytes(int64_t M);
+int nerf_mlp_backward(const void *packed, const float *params, const float *pos,
+                      const float *view_dir, int64_t M, int encoded, const float *sigma,
+                      const float *rgb, const void *saved, const float *g_sigma,
+                      const float *g_rgb, float *g_params, void *workspace,
+                      nerf_stream_t stream);
+
+/* ---- a11: QuadratureIntegrator.integrate_along_rays,
+ * R/renderer/integrators/quadrature_integrator.py:14-67
+ * sigma (n,S), radiance (n,S,3), delta (n,S) -> rgb (n,3), weights (n,S). */
+int nerf_composite_forward(const float *sigma, const float *radiance, const float *delta,
+                           int64_t n, int S, float *rgb, float *weights, nerf_stream_t stream);
+
+/* ---- a13 (integrator part): reverse of the quadrature rule.
+ * g_weights may be NULL (it is in the reference's runners). */
+int nerf_composite_backward(const float *sigma, const float *radiance, const float *delta,
+                            const float *g_rgb, const float *g_weights, int64_t n, int S,
+                            float *g_sigma, float *g_radiance, nerf_stream_t stream);
+
+/* ---- a3 + a12: one VolumeRenderer.render_scene pass (inference) on a ray range,
+ * R/renderer/volume_renderer.py:59-169, :192-261 -- the Python batch loop becomes a
+ * single enqueue of sample -> query -> integrate over `n` rays.
+ *   coarse pass: weights_in = NULL, u2 = u3 = NULL, Sf = 0
+ *   fine pass:   weights_in (n,Sc) is mutated in place like a7
+ * workspace: nerf_render_workspace_bytes(n, Sc+Sf). */
+int64_t nerf_render_workspace_bytes(int64_t n, int S);
+int nerf_render_rays(const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc,
+                     int Sf, const float *t_bins, float partition_size, float *weights_in,
+                     const float *u1, const float *u2, const float *u3, float *rgb,
+                     float *weights_out, void *workspace, nerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_AMD_H */

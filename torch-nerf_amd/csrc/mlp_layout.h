@@ -1,0 +1,95 @@
+// Geometry of the fused NeRF MLP kernels and of the packed weight stream they read.
+//
+// Network (R/network/nerf.py:49-59), fixed: 63 -> 256 x5 -> [63+256] -> 256 x3 -> 257 -> [256+27] -> 128 -> 3.
+//
+// The kernels evaluate Y^T = W . X^T with v_mfma_f32_32x32x2_f32: the WEIGHTS are the
+// A operand (M dimension = output features) and the ACTIVATIONS are the B operand
+// (N dimension = 32 samples of one wavefront).  The C/D fragment of that MFMA holds,
+// in lane (j = lane&31, h = lane>>5) and register r of feature block fb, output feature
+//      32*fb + (r&3) + 8*(r>>2) + 4*h          of sample j,
+// which is exactly the B-operand fragment (k = lane>>5) the NEXT layer needs if its
+// 16 MFMA k-steps for that 32-feature block walk r = 0..15.  Activations therefore
+// never leave registers between layers; only weights move (L2 -> LDS -> A operand).
+//
+// Packed stream = [const block][chunk 0][chunk 1]...[chunk 76], consumed linearly.
+// A chunk is the LDS image of W[:, 32 consecutive k] for one layer: 256 rows (output
+// features) x 128 B; row n holds eight 16-byte slots, logical slot c = (k%32)/4 is
+// stored at physical slot c ^ ((n>>1)&7) so that the ds_read_b128 of a 16-lane group
+// (16 distinct rows, same logical slot) touches 16 distinct 16-B slots of a 256-B bank
+// row: conflict-free.  The image is what the LDS-DMA copies verbatim (lane-linear).
+#pragma once
+#include <stdint.h>
+
+namespace mlp {
+
+constexpr int E_POS = 63, E_DIR = 27, FEAT = 256, HALF = 128;
+constexpr int L_POS = 10, L_DIR = 4;
+constexpr int NUM_LAYERS = 11;
+
+// flat parameter blob offsets (state_dict order, weight (out,in) then bias)
+struct LayerDim { int out, in; };
+constexpr LayerDim DIMS[NUM_LAYERS] = {{256, 63},  {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 319},
+                                       {256, 256}, {256, 256}, {257, 256}, {128, 283}, {3, 128}};
+constexpr int64_t w_offset(int l) {
+    int64_t off = 0;
+    for (int i = 0; i < l; ++i) off += (int64_t)DIMS[i].out * DIMS[i].in + DIMS[i].out;
+    return off;
+}
+constexpr int64_t b_offset(int l) { return w_offset(l) + (int64_t)DIMS[l].out * DIMS[l].in; }
+constexpr int64_t PARAM_COUNT = w_offset(NUM_LAYERS);  // 595844
+static_assert(PARAM_COUNT == 595844, "parameter count of NeRF(63, 27, 256)");
+
+// ---- const block (resident in LDS for the whole kernel), float offsets
+constexpr int CB_BIAS = 0;            // 8 x 256 : biases of fc_in, fc_1 .. fc_7
+constexpr int CB_BIAS8 = 2048;        // 256     : fc_8.bias[1:257]
+constexpr int CB_BIAS9 = 2304;        // 128     : fc_9.bias
+constexpr int CB_W8ROW0 = 2432;       // 256     : fc_8.weight[0, :]  (the density row)
+constexpr int CB_WOUT = 2688;         // 3 x 128 : fc_out.weight
+constexpr int CB_SCALARS = 3072;      // 4       : fc_8.bias[0], fc_out.bias[0..2]
+constexpr int CONST_FLOATS = 3328;    // padded to 13 KiB
+constexpr int CONST_BYTES = CONST_FLOATS * 4;
+
+// ---- weight chunks
+constexpr int CHUNK_ROWS = 256, CHUNK_K = 32;
+constexpr int CHUNK_BYTES = CHUNK_ROWS * CHUNK_K * 4;  // 32 KiB
+constexpr int CHUNK_FLOATS = CHUNK_BYTES / 4;
+// consumption order of the forward stream
+constexpr int CH_FC_IN = 0;    // 2 chunks : fc_in, k = encoded position (63 padded to 64)
+constexpr int CH_TRUNK1 = 2;   // 4 x 8    : fc_1 .. fc_4
+constexpr int CH_FC5_ENC = 34; // 2        : fc_5[:, 0:63]   (skip connection, pos first: nerf.py:108)
+constexpr int CH_FC5 = 36;     // 8        : fc_5[:, 63:319]
+constexpr int CH_TRUNK6 = 44;  // 2 x 8    : fc_6, fc_7
+constexpr int CH_FC8 = 60;     // 8        : fc_8 rows 1..256
+constexpr int CH_FC9 = 68;     // 9        : fc_9[:, 0:256] then fc_9[:, 256:283] (dir, padded to 32); rows 0..127
+constexpr int FWD_CHUNKS = 77;
+constexpr int64_t FWD_BYTES = (int64_t)CONST_BYTES + (int64_t)FWD_CHUNKS * CHUNK_BYTES;
+
+// ---- transposed stream for the backward dX chain (chunks of W^T: rows = INPUT feature,
+// k = output feature), appended after the forward stream.
+constexpr int BW_FC9T = 0;     // 4 chunks : fc_9[:, 0:256]^T     (rows 256 inputs, k = 128 outputs)
+constexpr int BW_FC8T = 4;     // 8        : fc_8[1:257, :]^T
+constexpr int BW_FC7T = 12;    // 8, then fc_6^T at 20
+constexpr int BW_FC5T = 28;    // 8        : fc_5[:, 63:319]^T
+constexpr int BW_FC4T = 36;    // 8 each: fc_4^T, fc_3^T, fc_2^T, fc_1^T
+constexpr int BWD_CHUNKS = 68;
+constexpr int64_t BWD_OFFSET = FWD_BYTES;
+constexpr int64_t PACKED_BYTES = FWD_BYTES + (int64_t)BWD_CHUNKS * CHUNK_BYTES;
+
+// ring of chunk slots in LDS
+constexpr int RING_SLOTS = 4;
+constexpr int LDS_BYTES = RING_SLOTS * CHUNK_BYTES + CONST_BYTES;  // 144384 <= 160 KiB
+
+// ---- activation record written by the training-mode forward (row-major planes)
+//   plane 0      : encoded position, 64 floats/sample (63 + one zero)
+//   planes 1..8  : post-ReLU outputs of fc_in, fc_1 .. fc_7, 256 floats/sample
+//   plane 9      : fc_8 output rows 1..256 (no ReLU), 256 floats/sample
+//   plane 10     : post-ReLU fc_9 output, 128 floats/sample
+//   plane 11     : encoded direction, 32 floats/sample (27 + zeros)
+constexpr int SAVED_FLOATS_PER_SAMPLE = 64 + 8 * 256 + 256 + 128 + 32;  // 2528
+constexpr int TILE_SAMPLES = 128;  // one workgroup pass: 4 wavefronts x 32 samples
+
+// physical byte offset, inside a chunk image, of the 16-byte slot holding
+// W[row n][k-group c] (c = (k % 32) / 4)
+__host__ __device__ constexpr int chunk_slot_offset(int n, int c) { return n * 128 + ((c ^ ((n >> 1) & 7)) << 4); }
+
+}  // namespace mlp

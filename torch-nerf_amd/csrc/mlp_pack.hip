@@ -1,0 +1,95 @@
+// Re-tiles the flat NeRF parameter blob (state_dict order) into the stream the fused
+// MLP kernels DMA into LDS: const block + 77 forward chunks + 68 transposed chunks
+// (layout: mlp_layout.h).  2.4 MB in, 4.8 MB out; runs once per parameter update.
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace {
+
+using namespace mlp;
+
+__device__ __forceinline__ float weight(const float *P, int layer, int n, int k) {
+    return P[w_offset(layer) + (int64_t)n * DIMS[layer].in + k];
+}
+
+__device__ float forward_chunk_value(const float *P, int ci, int n, int kk) {
+    if (ci < CH_TRUNK1) {
+        const int k = 32 * ci + kk;
+        return k < E_POS ? weight(P, 0, n, k) : 0.0f;
+    }
+    if (ci < CH_FC5_ENC) {
+        const int l = 1 + (ci - CH_TRUNK1) / 8, kb = (ci - CH_TRUNK1) % 8;
+        return weight(P, l, n, 32 * kb + kk);
+    }
+    if (ci < CH_FC5) {
+        const int k = 32 * (ci - CH_FC5_ENC) + kk;
+        return k < E_POS ? weight(P, 5, n, k) : 0.0f;
+    }
+    if (ci < CH_TRUNK6) return weight(P, 5, n, E_POS + 32 * (ci - CH_FC5) + kk);
+    if (ci < CH_FC8) {
+        const int l = 6 + (ci - CH_TRUNK6) / 8, kb = (ci - CH_TRUNK6) % 8;
+        return weight(P, l, n, 32 * kb + kk);
+    }
+    if (ci < CH_FC9) return weight(P, 8, n + 1, 32 * (ci - CH_FC8) + kk);
+    if (n >= HALF) return 0.0f;
+    if (ci < CH_FC9 + 8) return weight(P, 9, n, 32 * (ci - CH_FC9) + kk);
+    return kk < E_DIR ? weight(P, 9, n, FEAT + kk) : 0.0f;
+}
+
+// chunk of W^T: image row m = INPUT feature, k-group = 32 consecutive OUTPUT features
+__device__ float backward_chunk_value(const float *P, int ci, int m, int kk) {
+    if (ci < BW_FC8T) return weight(P, 9, 32 * (ci - BW_FC9T) + kk, m);
+    if (ci < BW_FC7T) return weight(P, 8, 1 + 32 * (ci - BW_FC8T) + kk, m);
+    if (ci < BW_FC5T) {
+        const int l = 7 - (ci - BW_FC7T) / 8, cb = (ci - BW_FC7T) % 8;
+        return weight(P, l, 32 * cb + kk, m);
+    }
+    if (ci < BW_FC4T) return weight(P, 5, 32 * (ci - BW_FC5T) + kk, E_POS + m);
+    const int l = 4 - (ci - BW_FC4T) / 8, cb = (ci - BW_FC4T) % 8;
+    return weight(P, l, 32 * cb + kk, m);
+}
+
+__device__ float const_block_value(const float *P, int e) {
+    if (e < CB_BIAS8) return P[b_offset(e / 256) + (e % 256)];
+    if (e < CB_BIAS9) return P[b_offset(8) + 1 + (e - CB_BIAS8)];
+    if (e < CB_W8ROW0) return P[b_offset(9) + (e - CB_BIAS9)];
+    if (e < CB_WOUT) return weight(P, 8, 0, e - CB_W8ROW0);
+    if (e < CB_SCALARS) return P[w_offset(10) + (e - CB_WOUT)];
+    if (e == CB_SCALARS) return P[b_offset(8)];
+    if (e < CB_SCALARS + 4) return P[b_offset(10) + (e - CB_SCALARS - 1)];
+    return 0.0f;
+}
+
+__global__ void pack_kernel(const float *__restrict__ P, float *__restrict__ out) {
+    const int64_t total = PACKED_BYTES / 4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (e < CONST_FLOATS) {
+            v = const_block_value(P, (int)e);
+        } else {
+            const int64_t r = e - CONST_FLOATS;
+            const int ci = (int)(r / CHUNK_FLOATS);
+            const int b = (int)(r % CHUNK_FLOATS) * 4;  // byte offset inside the chunk image
+            const int n = b >> 7;                       // row (128 B per row)
+            const int p = (b & 127) >> 4;               // physical 16-B slot
+            const int c = p ^ ((n >> 1) & 7);           // logical k-group
+            const int kk = 4 * c + ((b & 15) >> 2);
+            v = ci < FWD_CHUNKS ? forward_chunk_value(P, ci, n, kk)
+                                : backward_chunk_value(P, ci - FWD_CHUNKS, n, kk);
+        }
+        out[e] = v;
+    }
+}
+
+}  // namespace
+
+NERF_API int64_t nerf_mlp_param_count(void) { return mlp::PARAM_COUNT; }
+NERF_API int64_t nerf_mlp_packed_bytes(void) { return mlp::PACKED_BYTES; }
+
+NERF_API int nerf_mlp_pack(const float *params, void *packed, nerf_stream_t stream) {
+    NERF_REQUIRE(params && packed, "nerf_mlp_pack: null pointer");
+    hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, nerf::as_stream(stream), params,
+                       reinterpret_cast<float *>(packed));
+    return nerf::check_launch("nerf_mlp_pack");
+}

@@ -1,0 +1,303 @@
+"""Tensor-level wrappers over the C ABI and the torch.autograd.Function custom ops.
+
+Everything here launches HIP kernels on torch's current stream with raw device
+pointers of torch-allocated tensors.  PyTorch is plumbing (memory, streams, autograd
+graph); the arithmetic is in libnerf_amd.so.  No CPU fallback exists: a CPU tensor or
+a missing library raises.
+"""
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+_F32P = ctypes.POINTER(ctypes.c_float)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gpu(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name}: expected torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the HIP rendering path has no CPU fallback")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+# --------------------------------------------------------------------------- rays
+def screen_coords(height: int, width: int, device, pix: Optional[torch.Tensor] = None,
+                  first: int = 0, count: Optional[int] = None) -> torch.Tensor:
+    """(n,2) int64 screen coordinates on `device` (volume_renderer.py:171-190)."""
+    lib = _lib.load()
+    if pix is not None:
+        pix = _gpu(pix, "pix", torch.int64)
+        n = pix.numel()
+    else:
+        n = height * width - first if count is None else count
+    out = torch.empty((n, 2), dtype=torch.int64, device=device if pix is None else pix.device)
+    with torch.cuda.device(out.device):
+        _lib.check(lib.nerf_screen_coords(height, width, _ptr(pix), first, n, _ptr(out), _stream()),
+                   "nerf_screen_coords")
+    return out
+
+
+def generate_rays(height: int, width: int, intrinsic4: Sequence[float], extrinsic: torch.Tensor,
+                  project_to_ndc: bool, focal: float, z_near: float, device,
+                  coords: Optional[torch.Tensor] = None, pix: Optional[torch.Tensor] = None,
+                  first: int = 0, count: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Ray origins/directions (n,3) on the GPU (sampler_base.py:134-197, :199-257)."""
+    lib = _lib.load()
+    if coords is not None:
+        coords = _gpu(coords, "coords", torch.int64)
+        n, device = coords.shape[0], coords.device
+    elif pix is not None:
+        pix = _gpu(pix, "pix", torch.int64)
+        n, device = pix.numel(), pix.device
+    else:
+        n = height * width - first if count is None else count
+    ext = extrinsic.detach().to("cpu", torch.float32)[:3, :4].contiguous()
+    ext_host = (ctypes.c_float * 12)(*ext.reshape(-1).tolist())
+    o = torch.empty((n, 3), dtype=torch.float32, device=device)
+    d = torch.empty((n, 3), dtype=torch.float32, device=device)
+    fx, fy, cx, cy = (float(v) for v in intrinsic4)
+    with torch.cuda.device(o.device):
+        _lib.check(lib.nerf_generate_rays(_ptr(coords), _ptr(pix), first, n, height, width, fx, fy, cx, cy,
+                                          ext_host, int(bool(project_to_ndc)), float(focal),
+                                          float(z_near), _ptr(o), _ptr(d), _stream()),
+                   "nerf_generate_rays")
+    return o, d
+
+
+# --------------------------------------------------------------------------- sampling
+def sample_stratified(ray_o, ray_d, t_bins, partition_size: float, u1, want_t: bool = False):
+    """Coarse branch of StratifiedSampler.sample_along_rays -> (pts, dirs, delta[, t])."""
+    lib = _lib.load()
+    ray_o, ray_d, t_bins, u1 = _gpu(ray_o, "ray_o"), _gpu(ray_d, "ray_d"), _gpu(t_bins, "t_bins"), _gpu(u1, "u1")
+    n, S = u1.shape
+    dev = u1.device
+    pts = torch.empty((n, S, 3), dtype=torch.float32, device=dev)
+    dirs = torch.empty((n, S, 3), dtype=torch.float32, device=dev)
+    delta = torch.empty((n, S), dtype=torch.float32, device=dev)
+    t = torch.empty((n, S), dtype=torch.float32, device=dev) if want_t else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.nerf_sample_stratified(_ptr(ray_o), _ptr(ray_d), n, S, _ptr(t_bins),
+                                              float(partition_size), _ptr(u1), _ptr(t), _ptr(pts),
+                                              _ptr(dirs), _ptr(delta), _stream()),
+                   "nerf_sample_stratified")
+    return (pts, dirs, delta, t) if want_t else (pts, dirs, delta)
+
+
+def sample_hierarchical(ray_o, ray_d, t_bins, partition_size: float, weights, u1, u2, u3,
+                        want_idx: bool = False, want_t: bool = False):
+    """Hierarchical branch + sample_pdf.  `weights` (n,Sc) fp32 GPU is mutated in place (+1e-5)."""
+    lib = _lib.load()
+    if not (weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()):
+        raise RuntimeError("weights must be a contiguous fp32 GPU tensor (it is updated in place)")
+    ray_o, ray_d, t_bins = _gpu(ray_o, "ray_o"), _gpu(ray_d, "ray_d"), _gpu(t_bins, "t_bins")
+    u1, u2, u3 = _gpu(u1, "u1"), _gpu(u2, "u2"), _gpu(u3, "u3")
+    n, Sc = u1.shape
+    Sf = u2.shape[1]
+    S = Sc + Sf
+    dev = u1.device
+    pts = torch.empty((n, S, 3), dtype=torch.float32, device=dev)
+    dirs = torch.empty((n, S, 3), dtype=torch.float32, device=dev)
+    delta = torch.empty((n, S), dtype=torch.float32, device=dev)
+    idx = torch.empty((n, Sf), dtype=torch.int64, device=dev) if want_idx else None
+    t = torch.empty((n, S), dtype=torch.float32, device=dev) if want_t else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.nerf_sample_hierarchical(_ptr(ray_o), _ptr(ray_d), n, Sc, Sf, _ptr(t_bins),
+                                                float(partition_size), _ptr(weights), _ptr(u1), _ptr(u2),
+                                                _ptr(u3), _ptr(idx), _ptr(t), _ptr(pts), _ptr(dirs),
+                                                _ptr(delta), _stream()),
+                   "nerf_sample_hierarchical")
+    out = [pts, dirs, delta]
+    if want_idx:
+        out.append(idx)
+    if want_t:
+        out.append(t)
+    return tuple(out)
+
+
+# --------------------------------------------------------------------------- encoding
+def posenc(x: torch.Tensor, embed_level: int, include_input: bool) -> torch.Tensor:
+    lib = _lib.load()
+    x = _gpu(x, "in_signal")
+    if x.ndim != 2:
+        raise ValueError(f"Expected a 2D tensor (N, C). Got {x.ndim}-D.")
+    M, C = x.shape
+    E = 2 * embed_level * C + (C if include_input else 0)
+    out = torch.empty((M, E), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.nerf_posenc(_ptr(x), M, C, embed_level, int(bool(include_input)), _ptr(out),
+                                   _stream()), "nerf_posenc")
+    return out
+
+
+# --------------------------------------------------------------------------- MLP
+def mlp_param_count() -> int:
+    return int(_lib.load().nerf_mlp_param_count())
+
+
+def mlp_pack(flat_params: torch.Tensor) -> torch.Tensor:
+    """Flat state_dict blob (595844 fp32, GPU) -> packed LDS-image stream (uint8 GPU tensor)."""
+    lib = _lib.load()
+    flat_params = _gpu(flat_params, "flat_params")
+    if flat_params.numel() != lib.nerf_mlp_param_count():
+        raise ValueError(f"expected {lib.nerf_mlp_param_count()} parameters, got {flat_params.numel()}")
+    packed = torch.empty((lib.nerf_mlp_packed_bytes(),), dtype=torch.uint8, device=flat_params.device)
+    with torch.cuda.device(flat_params.device):
+        _lib.check(lib.nerf_mlp_pack(_ptr(flat_params), _ptr(packed), _stream()), "nerf_mlp_pack")
+    return packed
+
+
+def mlp_forward(packed: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor, encoded: bool,
+                save: bool = False):
+    """Fused encode + NeRF forward.  Returns (sigma (M,), rgb (M,3)[, saved])."""
+    lib = _lib.load()
+    pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
+    M = pos.shape[0]
+    sigma = torch.empty((M,), dtype=torch.float32, device=pos.device)
+    rgb = torch.empty((M, 3), dtype=torch.float32, device=pos.device)
+    saved = None
+    if save:
+        saved = torch.empty((lib.nerf_mlp_saved_bytes(M) // 4,), dtype=torch.float32, device=pos.device)
+    with torch.cuda.device(pos.device):
+        _lib.check(lib.nerf_mlp_forward(_ptr(packed), _ptr(pos), _ptr(view_dir), M, int(bool(encoded)),
+                                        _ptr(sigma), _ptr(rgb), _ptr(saved), _stream()),
+                   "nerf_mlp_forward")
+    return (sigma, rgb, saved) if save else (sigma, rgb)
+
+
+def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved, g_sigma, g_rgb):
+    """Parameter gradients as one flat tensor in state_dict order."""
+    lib = _lib.load()
+    M = pos.shape[0]
+    g_sigma, g_rgb = _gpu(g_sigma, "g_sigma"), _gpu(g_rgb, "g_rgb")
+    g_params = torch.empty((lib.nerf_mlp_param_count(),), dtype=torch.float32, device=pos.device)
+    ws_bytes = lib.nerf_mlp_backward_workspace_bytes(M)
+    ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=pos.device)
+    with torch.cuda.device(pos.device):
+        _lib.check(lib.nerf_mlp_backward(_ptr(packed), _ptr(flat_params), _ptr(pos), _ptr(view_dir), M,
+                                         int(bool(encoded)), _ptr(sigma), _ptr(rgb), _ptr(saved),
+                                         _ptr(g_sigma), _ptr(g_rgb), _ptr(g_params), _ptr(ws), _stream()),
+                   "nerf_mlp_backward")
+    return g_params
+
+
+class NerfMLPFunction(torch.autograd.Function):
+    """sigma, rgb = NeRF(encode(pos), encode(dir)) with hand-written forward and backward.
+
+    apply(pos, view_dir, encoded, packed, flat_params, *params): `params` are the 22
+    nn.Parameters in state_dict order (present so autograd routes their gradients);
+    `flat_params` is their concatenation and `packed` its LDS-image stream.
+    """
+
+    @staticmethod
+    def forward(ctx, pos, view_dir, encoded, packed, flat_params, *params):
+        need_grad = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        ctx.encoded = bool(encoded)
+        ctx.shapes = [p.shape for p in params]
+        if pos.requires_grad or view_dir.requires_grad:
+            raise RuntimeError("gradients w.r.t. sample positions / directions are not produced by the "
+                               "fused MLP kernel (the reference's runners never request them)")
+        if need_grad:
+            sigma, rgb, saved = mlp_forward(packed, pos, view_dir, encoded, save=True)
+            ctx.save_for_backward(pos, view_dir, packed, flat_params, sigma, rgb, saved)
+        else:
+            sigma, rgb = mlp_forward(packed, pos, view_dir, encoded, save=False)
+        return sigma, rgb
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb):
+        pos, view_dir, packed, flat_params, sigma, rgb, saved = ctx.saved_tensors
+        if g_sigma is None:
+            g_sigma = torch.zeros_like(sigma)
+        if g_rgb is None:
+            g_rgb = torch.zeros_like(rgb)
+        g_flat = mlp_backward(packed, flat_params, pos, view_dir, ctx.encoded, sigma, rgb, saved,
+                              g_sigma, g_rgb)
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for s in shp:
+                n *= s
+            grads.append(g_flat[off:off + n].view(shp))
+            off += n
+        return (None, None, None, None, None, *grads)
+
+
+# --------------------------------------------------------------------------- integrator
+def composite_forward(sigma, radiance, delta):
+    lib = _lib.load()
+    sigma, radiance, delta = _gpu(sigma, "sigma"), _gpu(radiance, "radiance"), _gpu(delta, "delta")
+    n, S = sigma.shape
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=sigma.device)
+    w = torch.empty((n, S), dtype=torch.float32, device=sigma.device)
+    with torch.cuda.device(sigma.device):
+        _lib.check(lib.nerf_composite_forward(_ptr(sigma), _ptr(radiance), _ptr(delta), n, S, _ptr(rgb),
+                                              _ptr(w), _stream()), "nerf_composite_forward")
+    return rgb, w
+
+
+def composite_backward(sigma, radiance, delta, g_rgb, g_w=None):
+    lib = _lib.load()
+    n, S = sigma.shape
+    g_rgb = _gpu(g_rgb, "g_rgb")
+    g_w = None if g_w is None else _gpu(g_w, "g_w")
+    gs = torch.empty((n, S), dtype=torch.float32, device=sigma.device)
+    gc = torch.empty((n, S, 3), dtype=torch.float32, device=sigma.device)
+    with torch.cuda.device(sigma.device):
+        _lib.check(lib.nerf_composite_backward(_ptr(sigma), _ptr(radiance), _ptr(delta), _ptr(g_rgb),
+                                               _ptr(g_w), n, S, _ptr(gs), _ptr(gc), _stream()),
+                   "nerf_composite_backward")
+    return gs, gc
+
+
+class CompositeFunction(torch.autograd.Function):
+    """rgb, w = quadrature integral; differentiable w.r.t. sigma and radiance."""
+
+    @staticmethod
+    def forward(ctx, sigma, radiance, delta):
+        sigma, radiance, delta = _gpu(sigma, "sigma"), _gpu(radiance, "radiance"), _gpu(delta, "delta")
+        rgb, w = composite_forward(sigma, radiance, delta)
+        ctx.save_for_backward(sigma, radiance, delta)
+        return rgb, w
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_w):
+        sigma, radiance, delta = ctx.saved_tensors
+        if g_rgb is None:
+            g_rgb = torch.zeros((sigma.shape[0], 3), dtype=torch.float32, device=sigma.device)
+        gs, gc = composite_backward(sigma, radiance, delta, g_rgb, g_w)
+        return gs, gc, None
+
+
+# --------------------------------------------------------------------------- fused pass
+def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, u2=None, u3=None):
+    """One inference render_scene pass as a single enqueue -> (rgb (n,3), weights (n,S))."""
+    lib = _lib.load()
+    ray_o, ray_d, t_bins, u1 = _gpu(ray_o, "ray_o"), _gpu(ray_d, "ray_d"), _gpu(t_bins, "t_bins"), _gpu(u1, "u1")
+    n, Sc = u1.shape
+    Sf = 0
+    if weights is not None:
+        u2, u3 = _gpu(u2, "u2"), _gpu(u3, "u3")
+        Sf = u2.shape[1]
+    S = Sc + Sf
+    dev = u1.device
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    w_out = torch.empty((n, S), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib.nerf_render_workspace_bytes(n, S),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nerf_render_rays(_ptr(packed), _ptr(ray_o), _ptr(ray_d), n, Sc, Sf, _ptr(t_bins),
+                                        float(partition_size), _ptr(weights), _ptr(u1), _ptr(u2), _ptr(u3),
+                                        _ptr(rgb), _ptr(w_out), _ptr(ws), _stream()), "nerf_render_rays")
+    return rgb, w_out
