@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s on 4096-ray x (64 coarse + 128 fine)-sample batches.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Workload (BASELINE.json configs[1]): Blender-lego geometry, 800x800, focal 1111.1, t in [2,6],
+no NDC, fp32, synthetic pose / pixels / weights (there is no dataset on the GPU box).
+One step = one VolumeRenderer.render_scene coarse pass (64 samples, coarse net) + one fine pass
+(64+128 sorted samples, fine net) over a 4096-ray batch per GPU, through the drop-in class API,
+forward only (rendering), inputs resident in HBM.  With N GPUs every rank renders its own
+4096-ray slab of the frame (weak scaling) and one all-gather assembles the N*4096 colours.
+
+The JSON line also carries
+  roofline     : the dominant kernel (fused posenc+MLP, fine-pass launch) against the fp32 MFMA
+                 peak, timed live with HIP events on the launch stream inside the timed region
+  cpu_baseline : the eager-PyTorch CPU port of the reference path (oracle/torch_port.py) on the
+                 host cores, same batch, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "torch-nerf_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+RAYS, N_COARSE, N_FINE = 4096, 64, 128
+H = W = 800
+NEAR, FAR = 2.0, 6.0
+MLP_FLOP_PER_SAMPLE = 2 * 593408
+FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
+
+
+def build_scene(device):
+    import torch_nerf.src.network as network
+    import torch_nerf.src.scene as scene
+    import torch_nerf.src.renderer.cameras as cameras
+    import torch_nerf.src.renderer.integrators.quadrature_integrator as integrators
+    import torch_nerf.src.renderer.ray_samplers as ray_samplers
+    from torch_nerf.src.renderer.volume_renderer import VolumeRenderer
+    from torch_nerf.src.signal_encoder import PositionalEncoder
+    from torch_nerf.amd import synth
+
+    focal = float(synth.blender_focal(W))
+    pose = torch.from_numpy(synth.pose_spherical(37.0, -30.0, 4.0))
+    cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H}, pose, NEAR, FAR)
+    enc = {"coord_enc": PositionalEncoder(3, 10, True), "dir_enc": PositionalEncoder(3, 4, True)}
+    nets, flats = [], []
+    for seed in (3, 4):
+        flat = synth.nerf_flat_params(seed=seed, sigma_bias=1.0, sigma_gain=30.0)
+        net = network.NeRF(63, 27)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.split_flat_params(flat).items()})
+        nets.append(net.to(device))
+        flats.append(flat)
+    renderer = VolumeRenderer(integrators.QuadratureIntegrator(), ray_samplers.StratifiedSampler(), cam)
+    return renderer, scene.PrimitiveCube(nets[0], enc), scene.PrimitiveCube(nets[1], enc), nets, flats, cam, focal, pose
+
+
+def render_step(renderer, scene_c, scene_f, pix, device_index):
+    """Exactly the two calls runners/train.py:172-201 / runner_utils.py:890-908 make per batch."""
+    c_rgb, c_idx, c_w = renderer.render_scene(scene_c, RAYS, N_COARSE, False, device_index, pixel_indices=pix)
+    f_rgb, _, f_w = renderer.render_scene(scene_f, RAYS, (N_COARSE, N_FINE), False, device_index,
+                                          pixel_indices=c_idx, weights=c_w)
+    return c_rgb, f_rgb
+
+
+def cpu_baseline(flats, focal, pose, device):
+    """Eager-torch CPU port on the host cores; returns the JSON object + PSNR of HIP vs port."""
+    from oracle import torch_port as TP
+    from torch_nerf.amd import ops, shard, synth
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    params = [{k: torch.from_numpy(v.copy()) for k, v in synth.split_flat_params(f).items()} for f in flats]
+
+    def run(n_rays):
+        pix = torch.from_numpy(synth.pixel_batch(0, H, W, n_rays))
+        draws = tuple(d.cpu() for d in shard.ray_draws(7, 0, n_rays, N_COARSE, N_FINE, "cpu"))
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = TP.render_batch(params[0], params[1], pix, H, W, focal, pose, NEAR, FAR, N_COARSE, N_FINE, draws)
+        return time.perf_counter() - t0, pix, draws, out
+
+    run(64)                                   # warm-up (thread pool, MKL)
+    t_probe, *_ = run(128)
+    n = int(min(RAYS, max(256, 128 * (12.0 / max(t_probe, 1e-3)))))   # aim at ~12 s of CPU work
+    n = max(256, (n // 256) * 256)
+    secs, pix, draws, (c_rgb, c_w, f_rgb, f_w, idx) = run(n)
+    # the HIP path on the same rays and draws: PSNR / max error of the pixel colours
+    k4 = (np.float32(focal), np.float32(focal), W / 2.0, H / 2.0)
+    o, d = ops.generate_rays(H, W, k4, pose, False, focal, NEAR, device, pix=pix.to(device))
+    t_bins = torch.linspace(NEAR, FAR, N_COARSE + 1, device=device)[:-1]
+    ps = (FAR - NEAR) / N_COARSE
+    u1c, u1, u2, u3 = (x.to(device) for x in draws)
+    pc, pf = (ops.mlp_pack(torch.from_numpy(f).to(device)) for f in flats)
+    g_c, g_w = ops.render_rays(pc, o, d, t_bins, ps, u1c)
+    g_f, _ = ops.render_rays(pf, o, d, t_bins, ps, u1, weights=g_w, u2=u2, u3=u3)
+    err = (g_f.cpu() - f_rgb).abs().max().item()
+    mse = torch.mean((g_f.cpu().double() - f_rgb.double()) ** 2).item()
+    psnr = float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)
+    base = {"value": n / secs, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of the 4096 rays of one batch, coarse 64 + fine 64+128, forward, eager PyTorch CPU "
+                      f"port of the reference path (oracle/torch_port.py), {cores} threads, {secs:.1f} s"}
+    quality = {"psnr_vs_cpu_port_db": (None if psnr == float("inf") else round(psnr, 2)),
+               "max_abs_pixel_err_vs_cpu_port": err, "coarse_max_abs_err": (g_c.cpu() - c_rgb).abs().max().item()}
+    return base, quality
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from torch_nerf.amd import ops
+    renderer, scene_c, scene_f, nets, flats, cam, focal, pose = build_scene(device)
+    total = H * W
+    n_steps = args.warmup + args.steps
+    # rank r renders slab (step*world + r) of the frame: contiguous 4096-pixel ranges, resident in HBM
+    pix = [((torch.arange(RAYS, device=device) + ((s * world + rank) * RAYS)) % total) for s in range(n_steps)]
+    gathered = torch.empty((world * RAYS, 3), device=device) if world > 1 else None
+    torch.manual_seed(1234 + rank)
+
+    def step(s):
+        _, f_rgb = render_step(renderer, scene_c, scene_f, pix[s], local_rank)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, f_rgb.contiguous())   # assemble the frame slab
+        return f_rgb
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for s in range(args.warmup):
+            step(s)
+        fence()
+        ops.KERNEL_EVENTS = []
+        t0 = time.perf_counter()
+        for s in range(args.warmup, n_steps):
+            step(s)
+        fence()
+        elapsed = time.perf_counter() - t0
+        events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # ---- dominant kernel: fused posenc+MLP, fine-pass launches (M = 4096 x 192)
+    fine = [(e0.elapsed_time(e1)) for tag, M, e0, e1 in events if M == RAYS * (N_COARSE + N_FINE)]
+    coarse = [(e0.elapsed_time(e1)) for tag, M, e0, e1 in events if M == RAYS * N_COARSE]
+    fine_ms = float(np.mean(fine))
+    achieved = RAYS * (N_COARSE + N_FINE) * MLP_FLOP_PER_SAMPLE / (fine_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("mlp_forward_fine_hbm_bytes_per_launch")
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "kernel": "mlp_forward_kernel<raw,inference> (fine pass, 786432 samples/launch)",
+                "ms_per_launch": round(fine_ms, 4), "coarse_ms_per_launch": round(float(np.mean(coarse)), 4),
+                "mlp_ms_per_step": round(fine_ms + float(np.mean(coarse)), 4)}
+
+    result = {
+        "metric": "rays/sec at 4096 rays x (64+128) samples",
+        "value": world * RAYS * args.steps / elapsed,
+        "unit": "rays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "Blender lego 800x800 geometry, 4096-ray batches, 64 coarse + 128 fine, fp32, "
+                               "forward render through VolumeRenderer.render_scene (coarse net + fine net)",
+                   "rays_per_gpu_per_step": RAYS, "global_rays_per_step": world * RAYS,
+                   "parallelism": f"ray-shard x{world}" + (" + all-gather" if world > 1 else "")},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, quality = cpu_baseline(flats, focal, pose, device)
+        result["cpu_baseline"] = base
+        result.update(quality)
+        result["speedup_vs_cpu_baseline"] = result["value"] / base["value"]
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+"""Host-side logic of the drop-in classes (no GPU): construction, validation, error
+behaviour and checkpoint layout mirror the reference; compute entry points refuse CPU
+tensors instead of silently falling back."""
+import numpy as np
+import pytest
+import torch
+
+import torch_nerf.src.network as network
+import torch_nerf.src.scene as scene
+import torch_nerf.src.renderer.cameras as cameras
+import torch_nerf.src.renderer.integrators.quadrature_integrator as integrators
+import torch_nerf.src.renderer.ray_samplers as ray_samplers
+from torch_nerf.src.renderer.volume_renderer import VolumeRenderer
+from torch_nerf.src.signal_encoder import PositionalEncoder, SHEncoder  # noqa: F401  (runner import line)
+from torch_nerf.amd import synth
+
+
+def _camera(h=6, w=5):
+    return cameras.PerspectiveCamera({"f_x": 10.0, "f_y": 10.0, "img_width": w, "img_height": h},
+                                     torch.eye(4), 2.0, 6.0)
+
+
+def test_camera_from_dict_and_tensor(golden):
+    g = golden("f1_raygen")
+    H, W, focal = g["blender_meta"][:3]
+    cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
+                                    torch.from_numpy(g["blender_pose"]), 2.0, 6.0)
+    assert np.array_equal(cam.intrinsic.numpy(), g["blender_intrinsic"])
+    assert (cam.img_height, cam.img_width) == (800, 800)
+    assert cam.focal_lengths == (float(focal), float(focal))
+    cam2 = cameras.PerspectiveCamera(cam.intrinsic, cam.extrinsic, 2.0, 6.0)
+    f32 = float(np.float32(focal))  # the tensor path reads the focal length back from fp32
+    assert (cam2.img_height, cam2.img_width, cam2.focal_lengths) == (800, 800, (f32, f32))
+    with pytest.raises(ValueError):
+        cameras.PerspectiveCamera([1, 2, 3], torch.eye(4), 2.0, 6.0)
+    with pytest.raises(ValueError):
+        cameras.PerspectiveCamera(torch.eye(3), torch.eye(4), 2.0, 6.0)
+    with pytest.raises(ValueError):
+        cam.extrinsic = torch.eye(3)
+    with pytest.raises(TypeError):  # the reference's setter calls isinstance(x, int, float)
+        cam.t_near = 1.0
+
+
+def test_screen_coords_table_matches_reference(golden):
+    g = golden("f1_raygen")
+    vr = VolumeRenderer(integrators.QuadratureIntegrator(), ray_samplers.StratifiedSampler(), _camera())
+    assert np.array_equal(vr.screen_coords.numpy(), g["small_coords_6x5"])
+    assert vr.screen_coords.dtype == torch.int64
+    vr.camera = _camera(4, 3)  # the setter invalidates the table
+    assert vr.screen_coords.shape == (12, 2)
+    empty = VolumeRenderer(integrators.QuadratureIntegrator(), ray_samplers.StratifiedSampler())
+    with pytest.raises(AssertionError):
+        empty.screen_coords
+
+
+def test_render_scene_argument_validation():
+    vr = VolumeRenderer(integrators.QuadratureIntegrator(), ray_samplers.StratifiedSampler(), _camera())
+    with pytest.raises(ValueError):
+        vr.render_scene(None, 4.0, 8, False, 0)
+    with pytest.raises(ValueError):
+        vr.render_scene(None, 4, (8, 8, 8), False, 0, pixel_indices=torch.arange(4))
+    with pytest.raises(ValueError):
+        vr.render_scene(None, 4, (8, 8), False, 0)
+
+
+def test_sampler_argument_validation():
+    s = ray_samplers.StratifiedSampler()
+    bundle = ray_samplers.RayBundle(torch.zeros(2, 3), torch.ones(2, 3), 2.0, 6.0, False)
+    with pytest.raises(ValueError):
+        s.sample_along_rays(bundle, (4, 4), "cpu")               # tuple without weights
+    with pytest.raises(ValueError):
+        s.sample_along_rays(bundle, 4, "cpu", weights=torch.ones(2, 4))  # int with weights
+    with pytest.raises(ValueError):
+        s.sample_along_rays(bundle, (4, 4), "cpu", weights=[1.0])
+    t_bins, ps = s._create_t_bins(2.0, 6.0, 64, "cpu")
+    assert t_bins.shape == (64,) and ps == 4.0 / 64
+    assert torch.equal(t_bins, torch.linspace(2.0, 6.0, 65)[:-1])
+    cam = cameras.PerspectiveCamera({"f_x": 10.0, "f_y": 11.0, "img_width": 4, "img_height": 4},
+                                    torch.eye(4), 0.0, 1.0)
+    with pytest.raises(ValueError):  # ambiguous focal length under NDC
+        s.generate_rays(torch.zeros(1, 2, dtype=torch.long), cam, True)
+
+
+def test_no_cpu_fallback():
+    s = ray_samplers.StratifiedSampler()
+    bundle = ray_samplers.RayBundle(torch.zeros(2, 3), torch.ones(2, 3), 2.0, 6.0, False)
+    with pytest.raises(RuntimeError, match="GPU"):
+        s.sample_along_rays(bundle, 4, "cpu")
+    with pytest.raises(RuntimeError, match="GPU"):
+        integrators.QuadratureIntegrator().integrate_along_rays(torch.ones(2, 4), torch.ones(2, 4, 3),
+                                                                torch.ones(2, 4))
+    with pytest.raises(RuntimeError, match="GPU"):
+        PositionalEncoder(3, 10, True).encode(torch.ones(4, 3))
+    net = network.NeRF(63, 27)
+    with pytest.raises(RuntimeError, match="GPU"):
+        net(torch.ones(4, 63), torch.ones(4, 27))
+
+
+def test_nerf_module_layout_and_errors():
+    net = network.NeRF(63, 27)
+    sd = net.state_dict()
+    expect = synth.split_flat_params(synth.nerf_flat_params(seed=0))
+    assert list(sd.keys()) == list(expect.keys())
+    assert all(tuple(sd[k].shape) == expect[k].shape for k in sd)
+    assert sum(p.numel() for p in net.parameters()) == 595844
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in expect.items()})
+    assert (net.pos_dim, net.view_dir_dim, net.feat_dim) == (63, 27, 256)
+    with pytest.raises(ValueError):
+        net(torch.ones(4, 63, 1), torch.ones(4, 27))
+    with pytest.raises(ValueError):
+        net(torch.ones(4, 63), torch.ones(5, 27))
+    with pytest.raises(ValueError):
+        net(torch.ones(4, 60), torch.ones(4, 27))
+    with pytest.raises(ValueError):
+        net(torch.ones(4, 63), torch.ones(4, 24))
+    with pytest.raises(NotImplementedError):
+        network.NeRF(60, 24, 128)(torch.ones(2, 60), torch.ones(2, 24))
+
+
+def test_positional_encoder_dims():
+    assert PositionalEncoder(3, 10, True).out_dim == 63
+    assert PositionalEncoder(3, 4, True).out_dim == 27
+    assert PositionalEncoder(3, 4, False).out_dim == 24
+    assert PositionalEncoder(3, 10, True).in_dim == 3
+
+
+def test_primitive_cube_contract():
+    enc = {"coord_enc": PositionalEncoder(3, 10, True), "dir_enc": PositionalEncoder(3, 4, True)}
+    net = network.NeRF(63, 27)
+    cube = scene.PrimitiveCube(net, enc)
+    assert cube.radiance_field is net and cube.encoders is enc and cube.fused_query
+    assert not scene.PrimitiveCube(net, {"coord_enc": PositionalEncoder(3, 8, True),
+                                         "dir_enc": PositionalEncoder(3, 4, True)}).fused_query
+    with pytest.raises(ValueError):
+        scene.PrimitiveCube("not a module", enc)
+    with pytest.raises(ValueError):
+        scene.PrimitiveCube(net, ["not", "a", "dict"])
+    with pytest.warns(UserWarning):
+        scene.PrimitiveCube(net, {"coord_enc": enc["coord_enc"]})
+    with pytest.raises(ValueError):
+        cube.encoders = {"coord_enc": enc["coord_enc"]}
+    with pytest.raises(ValueError):
+        cube.query_points(torch.ones(2, 4, 3), torch.ones(2, 5, 3))
+    assert isinstance(scene.Scene(cube), scene.Scene)
+
+
+def test_synthetic_generators_are_deterministic():
+    a = synth.nerf_flat_params(seed=5)
+    b = synth.nerf_flat_params(seed=5)
+    assert a.dtype == np.float32 and a.size == 595844 and np.array_equal(a, b)
+    assert not np.array_equal(a, synth.nerf_flat_params(seed=6))
+    assert abs(synth.blender_focal(800) - 1111.111) < 1e-2
+    assert len(synth.blender_orbit_poses()) == 40
+    p = synth.pixel_batch(0, 800, 800, 4096)
+    assert p.dtype == np.int64 and len(set(p.tolist())) == 4096

@@ -159,6 +159,20 @@ def mlp_pack(flat_params: torch.Tensor) -> torch.Tensor:
     return packed
 
 
+# When set to a list, every MLP launch appends (tag, M, start_event, end_event) recorded on the
+# launch stream: bench.py uses it to time the dominant kernel inside the timed region.
+KERNEL_EVENTS = None
+
+
+def _timed(tag, M):
+    if KERNEL_EVENTS is None:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    KERNEL_EVENTS.append((tag, M, e0, e1))
+    e0.record()
+    return e1
+
+
 def mlp_forward(packed: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor, encoded: bool,
                 save: bool = False):
     """Fused encode + NeRF forward.  Returns (sigma (M,), rgb (M,3)[, saved])."""
@@ -171,9 +185,12 @@ def mlp_forward(packed: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor,
     if save:
         saved = torch.empty((lib.nerf_mlp_saved_bytes(M) // 4,), dtype=torch.float32, device=pos.device)
     with torch.cuda.device(pos.device):
+        end = _timed("mlp_forward", M)
         _lib.check(lib.nerf_mlp_forward(_ptr(packed), _ptr(pos), _ptr(view_dir), M, int(bool(encoded)),
                                         _ptr(sigma), _ptr(rgb), _ptr(saved), _stream()),
                    "nerf_mlp_forward")
+        if end is not None:
+            end.record()
     return (sigma, rgb, saved) if save else (sigma, rgb)
 
 

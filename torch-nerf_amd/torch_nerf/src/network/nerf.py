@@ -1,0 +1,95 @@
+"""The NeRF MLP as an nn.Module whose forward and backward are hand-written HIP kernels.
+
+Interface of torch_nerf/src/network/nerf.py:12-136: NeRF(pos_dim, view_dir_dim, feat_dim=256),
+forward(pos (M,pos_dim), view_dir (M,view_dir_dim)) -> (sigma (M,), rgb (M,3)), the same
+ValueErrors, and the same parameter names fc_in, fc_1 .. fc_9, fc_out (.weight (out,in),
+.bias) so the reference's checkpoints (runner_utils.py:758-775) load unchanged.
+
+The eleven nn.Linear modules only HOLD the parameters (default init, state_dict layout,
+optimizer visibility); they are never called.  The arithmetic is csrc/mlp_forward.hip /
+mlp_backward.hip behind torch_nerf.amd.ops.NerfMLPFunction.  The kernels are specialised
+for the reference's configured architecture (63 / 27 / 256, configs/network/nerf.yaml +
+signal_encoder/positional_encoding.yaml); other sizes raise -- there is no slow path.
+"""
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+from torch_nerf.amd import ops
+
+__all__ = ["NeRF"]
+
+_LAYERS = ("fc_in", "fc_1", "fc_2", "fc_3", "fc_4", "fc_5", "fc_6", "fc_7", "fc_8", "fc_9", "fc_out")
+
+
+class NeRF(nn.Module):
+    def __init__(self, pos_dim: int, view_dir_dim: int, feat_dim: int = 256):
+        super().__init__()
+        self._pos_dim, self._view_dir_dim, self._feat_dim = pos_dim, view_dir_dim, feat_dim
+        f = feat_dim
+        widths_in = (pos_dim, f, f, f, f, f + pos_dim, f, f, f, f + view_dir_dim, f // 2)
+        widths_out = (f, f, f, f, f, f, f, f, f + 1, f // 2, 3)
+        for name, i, o in zip(_LAYERS, widths_in, widths_out):
+            setattr(self, name, nn.Linear(i, o))
+        self.relu_actvn = nn.ReLU()        # kept for module-tree parity; unused
+        self.sigmoid_actvn = nn.Sigmoid()
+        self._pack_key = None
+        self._flat = None
+        self._packed = None
+
+    # ------------------------------------------------------------------ parameters -> kernel stream
+    def _ordered_params(self):
+        out = []
+        for name in _LAYERS:
+            layer = getattr(self, name)
+            out += [layer.weight, layer.bias]
+        return out
+
+    def _stream(self):
+        """(flat blob, packed LDS-image stream), rebuilt only when a parameter changed."""
+        if (self._pos_dim, self._view_dir_dim, self._feat_dim) != (63, 27, 256):
+            raise NotImplementedError(
+                "the HIP kernels are built for NeRF(pos_dim=63, view_dir_dim=27, feat_dim=256); "
+                f"got ({self._pos_dim}, {self._view_dir_dim}, {self._feat_dim})")
+        params = self._ordered_params()
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key != self._pack_key:
+            if not params[0].is_cuda:
+                raise RuntimeError("NeRF parameters must be on the GPU: the HIP path has no CPU fallback")
+            with torch.no_grad():
+                self._flat = torch.cat([p.detach().reshape(-1) for p in params]).float().contiguous()
+                self._packed = ops.mlp_pack(self._flat)
+            self._pack_key = key
+        return params, self._flat, self._packed
+
+    # ------------------------------------------------------------------ forward paths
+    def forward(self, pos: torch.Tensor, view_dir: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """pos (M,63), view_dir (M,27): already encoded.  sigma = relu(.), rgb = sigmoid(.)."""
+        if (pos.ndim != 2) or (view_dir.ndim != 2):
+            raise ValueError(f"Expected 2D tensors. Got {pos.ndim}, {view_dir.ndim}-D tensors.")
+        if pos.shape[0] != view_dir.shape[0]:
+            raise ValueError(f"The number of samples must match. Got {pos.shape[0]} and {view_dir.shape[0]}.")
+        if pos.shape[-1] != self._pos_dim:
+            raise ValueError(f"Expected {self._pos_dim}-D position vector. Got {pos.shape[-1]}.")
+        if view_dir.shape[-1] != self._view_dir_dim:
+            raise ValueError(f"Expected {self._view_dir_dim}-D view direction vector. Got {view_dir.shape[-1]}.")
+        params, flat, packed = self._stream()
+        return ops.NerfMLPFunction.apply(pos, view_dir, True, packed, flat, *params)
+
+    def accepts_fused_encoders(self, coord_enc, dir_enc) -> bool:
+        """True if the two encoders are exactly what the fused kernel computes in registers."""
+        def is_pe(e, level):
+            return (type(e).__name__ == "PositionalEncoder" and getattr(e, "in_dim", None) == 3
+                    and getattr(e, "embed_level", None) == level and getattr(e, "include_input", False))
+        return (self._pos_dim, self._view_dir_dim, self._feat_dim) == (63, 27, 256) and \
+            is_pe(coord_enc, 10) and is_pe(dir_enc, 4)
+
+    def forward_fused(self, points: torch.Tensor, view_dirs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """points, view_dirs (M,3) RAW: positional encoding happens inside the kernel."""
+        params, flat, packed = self._stream()
+        return ops.NerfMLPFunction.apply(points, view_dirs, False, packed, flat, *params)
+
+    pos_dim = property(lambda self: self._pos_dim)
+    view_dir_dim = property(lambda self: self._view_dir_dim)
+    feat_dim = property(lambda self: self._feat_dim)

@@ -1,0 +1,128 @@
+"""Volume renderer: pixel choice -> rays -> samples -> query -> integrate, on the GPU.
+
+Drop-in for torch_nerf/src/renderer/volume_renderer.py (VolumeRenderer :14-289): same
+constructor, `render_scene` signature / validation / return convention
+(rgb on device, pixel indices as an int64 CPU tensor, weights on device) and the same
+`camera` / `integrator` / `sampler` / `screen_coords` properties.
+
+What changed underneath:
+  * the (H*W, 2) screen-coordinate table is evaluated inside the ray-generation kernel
+    from the flat pixel index; the CPU table is only materialised if `screen_coords` is read
+  * sampling, encoding+MLP and the integral are three HIP kernels per pass; the Python loop
+    over ray batches (:229-254) is gone -- activations live in registers, so there is
+    nothing to run out of memory on; `num_ray_batch` is accepted and ignored for scenes
+    that expose the fused query, and honoured for any other `target_scene`
+"""
+from typing import Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+import torch_nerf.src.renderer.cameras as cameras
+import torch_nerf.src.renderer.integrators.quadrature_integrator as integrators
+import torch_nerf.src.renderer.ray_samplers as ray_samplers
+import torch_nerf.src.scene as scene
+
+
+class VolumeRenderer(object):
+    def __init__(self, integrator: integrators.IntegratorBase, sampler: ray_samplers.RaySamplerBase,
+                 camera: Optional[cameras.PerspectiveCamera] = None):
+        self._integrator = integrator
+        self._sampler = sampler
+        self._camera = camera
+        self._screen_coords = None  # built lazily, see the `screen_coords` property
+        if not self._camera:
+            print("Warning: Camera parameters are not initialized.")
+
+    # ------------------------------------------------------------------ rendering
+    def render_scene(self, target_scene: scene.PrimitiveBase, num_pixels: int,
+                     num_samples: Union[int, Tuple[int, int]], project_to_ndc: bool, device: int,
+                     pixel_indices: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None,
+                     num_ray_batch: int = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Returns (pixel_rgb (N,3), pixel_to_render (N,) int64 on the CPU, weights (N,S))."""
+        if not isinstance(num_pixels, int):
+            raise ValueError(f"Expected variable of type int. Got {type(num_pixels)}.")
+        if isinstance(num_samples, (tuple, list)):
+            if len(num_samples) != 2:
+                raise ValueError("Expected a tuple of length 2 for num_samples of type tuple. "
+                                 f"Got a tuple of length {len(num_samples)}.")
+            if pixel_indices is None:
+                raise ValueError("Expected a predefined set of pixels to render in hierarchical sampling. "
+                                 "Pixel indices are not provided.")
+
+        cam = self.camera
+        total = cam.img_height * cam.img_width
+        whole_frame = False
+        if pixel_indices is not None:
+            pixel_to_render = pixel_indices
+        elif num_pixels < total:
+            # same call as the reference (:121-128): numpy's global RNG, sampling without replacement
+            pixel_to_render = torch.tensor(np.random.choice(total, size=[num_pixels], replace=False))
+        else:
+            pixel_to_render = torch.arange(0, total)
+            whole_frame = True
+
+        gen = getattr(self.sampler, "generate_rays_from_pixels", None)
+        if gen is not None:
+            dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+            if whole_frame:
+                ray_bundle = gen(cam, project_to_ndc, first=0, count=total, device=dev)
+            else:
+                ray_bundle = gen(cam, project_to_ndc, pixel_indices=pixel_to_render, device=dev)
+        else:  # a foreign sampler: go through the coordinate table like the reference
+            coords = self.screen_coords.clone()[pixel_to_render, :]
+            ray_bundle = self.sampler.generate_rays(coords, cam, project_to_ndc=project_to_ndc)
+
+        sample_pts, ray_dir, delta_t = self.sampler.sample_along_rays(ray_bundle, num_samples, device=device,
+                                                                      weights=weights)
+        pixel_rgb, weights, _, _ = self._render_ray_batches(
+            target_scene, sample_pts, ray_dir, delta_t, num_batch=1 if num_ray_batch is None else num_ray_batch)
+        return pixel_rgb, pixel_to_render, weights
+
+    def _generate_screen_coords(self) -> torch.Tensor:
+        """(H*W, 2) int64: column 0 = x, column 1 = H-1-row (rows flipped)."""
+        h, w = self.camera.img_height, self.camera.img_width
+        flat = torch.arange(h * w)
+        return torch.stack([flat % w, (h - 1) - torch.div(flat, w, rounding_mode="floor")], dim=-1)
+
+    def _render_ray_batches(self, target_scene, sample_pts: torch.Tensor, ray_dir: torch.Tensor,
+                            delta_t: torch.Tensor, num_batch: int):
+        """-> (pixel_rgb (N,3), weights (N,S), sigma (N,S), radiance (N,S,3))."""
+        if getattr(target_scene, "fused_query", False) or num_batch <= 1:
+            sigma, radiance = target_scene.query_points(sample_pts, ray_dir)
+            rgb, weights = self.integrator.integrate_along_rays(sigma, radiance, delta_t)
+            return rgb, weights, sigma, radiance
+        n = sample_pts.shape[0]
+        cuts = torch.linspace(0, n, num_batch + 1, dtype=torch.long)
+        cuts[-1] = n
+        parts = []
+        for lo, hi in zip(cuts[:-1].tolist(), cuts[1:].tolist()):
+            s, c = target_scene.query_points(sample_pts[lo:hi], ray_dir[lo:hi])
+            r, w = self.integrator.integrate_along_rays(s, c, delta_t[lo:hi])
+            parts.append((r, w, s, c))
+        return tuple(torch.cat(col, dim=0) for col in zip(*parts))
+
+    # ------------------------------------------------------------------ accessors
+    @property
+    def camera(self) -> cameras.PerspectiveCamera:
+        return self._camera
+
+    @camera.setter
+    def camera(self, new_camera: cameras.PerspectiveCamera) -> None:
+        self._camera = new_camera
+        self._screen_coords = None  # the reference rebuilds the table here; we defer it
+
+    @property
+    def integrator(self) -> integrators.IntegratorBase:
+        return self._integrator
+
+    @property
+    def sampler(self) -> ray_samplers.RaySamplerBase:
+        return self._sampler
+
+    @property
+    def screen_coords(self) -> torch.Tensor:
+        assert self._camera is not None, "Screen coordinates must not be None at rendering time."
+        if self._screen_coords is None:
+            self._screen_coords = self._generate_screen_coords()
+        return self._screen_coords
