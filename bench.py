@@ -72,16 +72,28 @@ def render_step(renderer, scene_c, scene_f, pix, device_index):
     return c_rgb, f_rgb
 
 
-def cpu_baseline(flats, focal, pose, device):
-    """Eager-torch CPU port on the host cores; returns the JSON object + PSNR of HIP vs port."""
-    from oracle import torch_port as TP
-    from torch_nerf.amd import ops, shard, synth
-
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(np.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline(flats, focal, pose, device):
+    """Eager-torch CPU port on the host cores; returns the JSON object + PSNR of HIP vs port."""
+    from oracle import torch_port as TP
+    from torch_nerf.amd import ops, shard, synth
+
+    cores = host_cores()
     torch.set_num_threads(cores)
     params = [{k: torch.from_numpy(v.copy()) for k, v in synth.split_flat_params(f).items()} for f in flats]
 
@@ -94,10 +106,14 @@ def cpu_baseline(flats, focal, pose, device):
         return time.perf_counter() - t0, pix, draws, out
 
     run(64)                                   # warm-up (thread pool, MKL)
-    t_probe, *_ = run(128)
-    n = int(min(RAYS, max(256, 128 * (12.0 / max(t_probe, 1e-3)))))   # aim at ~12 s of CPU work
+    t_probe, *_ = run(256)
+    n = int(min(RAYS, max(256, 256 * (12.0 / max(t_probe, 1e-3)))))   # aim at ~12 s of CPU work
     n = max(256, (n // 256) * 256)
     secs, pix, draws, (c_rgb, c_w, f_rgb, f_w, idx) = run(n)
+    if secs < 8.0:                            # fast host: repeat the full batch to reach ~10 s
+        reps = int(min(8, max(1, round(10.0 / secs) - 1)))
+        extra = [run(n)[0] for _ in range(reps)]
+        secs = (secs + sum(extra)) / (1 + reps)
     # the HIP path on the same rays and draws: PSNR / max error of the pixel colours
     k4 = (np.float32(focal), np.float32(focal), W / 2.0, H / 2.0)
     o, d = ops.generate_rays(H, W, k4, pose, False, focal, NEAR, device, pix=pix.to(device))
@@ -112,7 +128,7 @@ def cpu_baseline(flats, focal, pose, device):
     psnr = float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)
     base = {"value": n / secs, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": f"{n} of the 4096 rays of one batch, coarse 64 + fine 64+128, forward, eager PyTorch CPU "
-                      f"port of the reference path (oracle/torch_port.py), {cores} threads, {secs:.1f} s"}
+                      f"port of the reference path (oracle/torch_port.py), {cores} threads, {secs:.1f} s per pass"}
     quality = {"psnr_vs_cpu_port_db": (None if psnr == float("inf") else round(psnr, 2)),
                "max_abs_pixel_err_vs_cpu_port": err, "coarse_max_abs_err": (g_c.cpu() - c_rgb).abs().max().item()}
     return base, quality
@@ -173,20 +189,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    # ---- dominant kernel: fused posenc+MLP, fine-pass launches (M = 4096 x 192)
-    fine = [(e0.elapsed_time(e1)) for tag, M, e0, e1 in events if M == RAYS * (N_COARSE + N_FINE)]
-    coarse = [(e0.elapsed_time(e1)) for tag, M, e0, e1 in events if M == RAYS * N_COARSE]
-    fine_ms = float(np.mean(fine))
-    achieved = RAYS * (N_COARSE + N_FINE) * MLP_FLOP_PER_SAMPLE / (fine_ms * 1e-3) / 1e12
+    # ---- dominant kernel: fused posenc+MLP (mlp_forward_kernel), two launches per step:
+    # coarse pass M = 4096 x 64 and fine pass M = 4096 x 192.  achieved = algorithmic FLOPs of all its
+    # launches in the timed region / their summed HIP-event durations; ms_per_launch = their mean
+    # (what rocprofv3 --stats reports as the kernel's average).
+    durs = [(M, e0.elapsed_time(e1)) for tag, M, e0, e1 in events if tag == "mlp_forward"]
+    total_ms = sum(ms for _, ms in durs)
+    total_flop = sum(M for M, _ in durs) * MLP_FLOP_PER_SAMPLE
+    achieved = total_flop / (total_ms * 1e-3) / 1e12
+    fine_ms = float(np.mean([ms for M, ms in durs if M == RAYS * (N_COARSE + N_FINE)]))
+    coarse_ms = float(np.mean([ms for M, ms in durs if M == RAYS * N_COARSE]))
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("mlp_forward_fine_hbm_bytes_per_launch")
+        traffic = json.load(open(tpath)).get("mlp_forward_hbm_bytes_per_launch")
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "kernel": "mlp_forward_kernel<raw,inference> (fine pass, 786432 samples/launch)",
-                "ms_per_launch": round(fine_ms, 4), "coarse_ms_per_launch": round(float(np.mean(coarse)), 4),
-                "mlp_ms_per_step": round(fine_ms + float(np.mean(coarse)), 4)}
+                "kernel": "mlp_forward_kernel<false,false> (fused posenc + 11-layer MLP), 2 launches/step",
+                "launches": len(durs), "ms_per_launch": round(total_ms / len(durs), 4),
+                "fine_ms_per_launch": round(fine_ms, 4), "coarse_ms_per_launch": round(coarse_ms, 4),
+                "flop_per_launch_avg": total_flop / len(durs)}
 
     result = {
         "metric": "rays/sec at 4096 rays x (64+128) samples",
