@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from torch_nerf.amd import synth
+from helpers import check_grad_digest
 
 
 def _bits(a):
@@ -79,21 +80,6 @@ def test_posenc(golden, oracle):
 GRAD_KW = {"default": dict(seed=1), "dense": dict(seed=2, sigma_bias=1.0, sigma_gain=30.0)}
 
 
-def _check_grad_digest(flat_grad, g, prefix, rtol, atol_scale):
-    grads = synth.split_flat_params(flat_grad)
-    for k, v in grads.items():
-        v = v.reshape(-1)
-        norm_ref = float(g[prefix + k + ".norm"][0])
-        atol = atol_scale * max(norm_ref / np.sqrt(v.size), 1e-12)
-        head = g[prefix + k + ".head"]
-        strided = g[prefix + k + ".stride"]
-        np.testing.assert_allclose(v[:head.size], head, rtol=rtol, atol=atol, err_msg=k)
-        step = max(1, v.size // 192)
-        np.testing.assert_allclose(v[::step][:strided.size], strided, rtol=rtol, atol=atol, err_msg=k)
-        norm = np.sqrt(np.sum(v.astype(np.float64) ** 2))
-        assert abs(norm - norm_ref) <= 1e-4 * norm_ref + 1e-12, k
-
-
 @pytest.mark.parametrize("tag", ["default", "dense"])
 def test_mlp_forward_backward(golden, oracle, tag):
     g = golden("f5_mlp")
@@ -105,7 +91,7 @@ def test_mlp_forward_backward(golden, oracle, tag):
     np.testing.assert_allclose(sigma, g[tag + "_sigma"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(rgb, g[tag + "_rgb"], rtol=0, atol=1e-5)
     grad = oracle.mlp_backward(flat, pe, de, g[tag + "_g_sigma"], g[tag + "_g_rgb"])
-    _check_grad_digest(grad, g, tag + "_grad_", rtol=2e-4, atol_scale=2e-3)
+    check_grad_digest(grad, g, tag + "_grad_", rtol=2e-4, atol_scale=2e-3)
 
 
 @pytest.mark.parametrize("S", [64, 192, 7])

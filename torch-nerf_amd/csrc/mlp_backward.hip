@@ -1,11 +1,505 @@
-// a13 (MLP part): parameter gradients.  Placeholder until the MFMA backward lands.
-#include "common.h"
-#include "mlp_layout.h"
+// a13 (MLP part): gradients of the 22 parameter tensors of NeRF(63, 27, 256).
+//
+// The reference obtains them from autograd (entered at runners/train.py:215, per layer
+// mm x2 + threshold_backward + sum).  Here the reverse pass is three hand-written stages:
+//
+//  1. dX chain   (mlp_bwd_dx_kernel): same register-resident structure as the forward --
+//     32 samples per wavefront, dY^T(l-1) = W_l^T dY^T(l) on v_mfma_f32_32x32x2_f32 with the
+//     TRANSPOSED weight chunks streamed through the LDS ring -- ReLU masks come from the
+//     bit planes the training-mode forward saved; every layer's pre-activation gradient is
+//     written once to a row-major plane.  8704 MFMAs per 32 samples.
+//  2. dW GEMMs   (mlp_bwd_dw_kernel): dW_l = dY_l^T X_l with the sample axis as the MFMA
+//     reduction dimension.  A workgroup owns one (layer, sample-slice) item, keeps the whole
+//     256 x K_l tile in accumulators (up to 256 VGPRs per lane), and streams 32-row tiles of
+//     dY and X -- contiguous in HBM -- into a double-buffered LDS stage by LDS-DMA.
+//     Bias gradients and the density row of fc_8 ride along as vector-ALU side jobs.
+//     2 KB of HBM reads per sample-layer for 131 kFLOP: intensity 64 FLOP/B, MFMA-bound.
+//  3. a deterministic reduction of the per-slice partial tiles into the flat gradient blob
+//     (state_dict layout), plus a small vector kernel for fc_out (3 x 128).
+#include "mlp_device.h"
 
-NERF_API int64_t nerf_mlp_backward_workspace_bytes(int64_t M) { (void)M; return 0; }
+namespace {
 
-NERF_API int nerf_mlp_backward(const void *, const float *, const float *, const float *, int64_t, int,
-                               const float *, const float *, const void *, const float *, const float *,
-                               float *, void *, nerf_stream_t) {
-    return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_mlp_backward: not implemented yet");
+using namespace mlp;
+
+// ------------------------------------------------------------------------------------------
+// stage 1: dX chain
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool mask_bit(const u32x4 &mk, int fb, int r) {
+    return (mk[fb >> 1] >> (16 * (fb & 1) + r)) & 1u;
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restrict__ packed, int64_t M,
+                                                             const float *__restrict__ sigma,
+                                                             const float *__restrict__ rgb,
+                                                             const float *__restrict__ g_sigma,
+                                                             const float *__restrict__ g_rgb,
+                                                             const float *__restrict__ saved,
+                                                             float *__restrict__ dy) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    float *cb = reinterpret_cast<float *>(lds + RING_SLOTS * CHUNK_BYTES);
+    for (int e = tid; e < CONST_FLOATS / 4; e += 256)
+        reinterpret_cast<f32x4 *>(cb)[e] = reinterpret_cast<const f32x4 *>(packed)[e];
+
+    int offq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) offq[q] = chunk_slot_offset(i, 2 * q + h);
+
+    Pipe pipe;
+    pipe.src_lane = packed + BWD_OFFSET + wave * 8192 + lane * 16;
+    pipe.lds_wave =
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 8192u;
+    pipe.issued = 0;
+    pipe.issue_pos = 0;
+    pipe.consumed = 0;
+    pipe.n_chunks = BWD_CHUNKS;
+    __syncthreads();
+    pipe.issue();
+    pipe.issue();
+    pipe.issue();
+
+    const int64_t MP = padded_rows(M);
+    const u32x4 *masks = reinterpret_cast<const u32x4 *>(saved + pl_masks(MP));
+    const int64_t ntiles = MP / TILE_SAMPLES;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t m = tile * TILE_SAMPLES + wave * 32 + i;
+        const bool valid = m < M;
+        const int64_t mc = valid ? m : M - 1;
+
+        // fc_out + sigmoid (nerf.py:119): d y10 = g_rgb * rgb * (1 - rgb)
+        float gy[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float y = rgb[3 * mc + c];
+            gy[c] = valid ? g_rgb[3 * mc + c] * y * (1.0f - y) : 0.0f;
+        }
+        // sigma = relu(y8[0]) (nerf.py:115)
+        const float dsig = (valid && sigma[mc] > 0.0f) ? g_sigma[mc] : 0.0f;
+
+        f32x16 acc[8], act[8];
+
+        // ---- dY9 = (W_out^T d y10) . [h9 > 0]   (vector ALU, 3 x 128 MACs per sample)
+        {
+            const u32x4 mk = masks[(int64_t)8 * MP * 2 + 2 * m + h];
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k0 = 32 * fb + 8 * q + 4 * h;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(cb + CB_WOUT + k0);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(cb + CB_WOUT + HALF + k0);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4 *>(cb + CB_WOUT + 2 * HALF + k0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = fmaf(w2[j], gy[2], fmaf(w1[j], gy[1], w0[j] * gy[0]));
+                        act[fb][4 * q + j] = mask_bit(mk, fb, 4 * q + j) ? v : 0.0f;
+                    }
+                }
+        }
+        save_plane<4>(dy + dy9_plane(MP), 128, m, valid, h, act);
+
+        // ---- d y8[1:257] = W9[:, 0:256]^T dY9   (fc_9 input is cat([x[:,1:], dir]): nerf.py:116)
+#pragma unroll
+        for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) mma_chunk<8>(acc, act[kb], lds + pipe.acquire(), offq);
+#pragma unroll
+        for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];  // fc_8 has no ReLU
+        save_plane<8>(dy + dy_plane(MP, 8), 256, m, valid, h, act);
+        if (h == 0) dy[dsig_plane(MP) + m] = dsig;
+
+        // ---- l = 8 .. 1:  dY(l-1) = (W_l^T dY(l)) . [h(l-1) > 0]
+        for (int l = 8; l >= 1; --l) {
+            if (l == 8) {  // the density row of fc_8 contributes w8[0, k] * d y8[0]
+#pragma unroll
+                for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 w = *reinterpret_cast<const f32x4 *>(cb + CB_W8ROW0 + 32 * fb + 8 * q + 4 * h);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[fb][4 * q + j] = w[j] * dsig;
+                    }
+            } else {
+#pragma unroll
+                for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) mma_chunk<8>(acc, act[kb], lds + pipe.acquire(), offq);
+            const u32x4 mk = masks[(int64_t)(l - 1) * MP * 2 + 2 * m + h];
+#pragma unroll
+            for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[fb][r] = mask_bit(mk, fb, r) ? acc[fb][r] : 0.0f;
+            save_plane<8>(dy + dy_plane(MP, l - 1), 256, m, valid, h, act);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 2: dW GEMMs
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_GEMMS = 13;
+constexpr int SLICE_EXTRA = 1024;  // floats reserved after each partial tile: bias (<=256) + density row (<=257)
+constexpr int STAGE_BYTES = 65536;  // A tile (<= 32 KiB) + X tile (<= 32 KiB)
+constexpr int DW_LDS_BYTES = 2 * STAGE_BYTES;
+enum { FLAG_BIAS = 1, FLAG_DENSITY = 2 };
+
+struct GemmDesc {
+    int64_t a_off;        // dY plane, float offset into the dy workspace
+    int64_t x_off;        // X plane, float offset into the saved record
+    int64_t partial_off;  // float offset of slice 0 in the partial buffer
+    int64_t w_off;        // destination: weight tensor offset in the flat gradient
+    int64_t b_off;        // destination: bias offset (row0 already applied by the reducer)
+    int a_width;          // 256 | 128  (output features of the layer = rows of dW)
+    int x_width;          // 256 | 64 | 32 (padded input features of this column block)
+    int first_block, num_slices;
+    int flags;
+    int in_features;      // row stride of the destination weight tensor
+    int col0, valid_cols; // destination column block
+    int row0;             // destination row offset (1 for fc_8: row 0 is the density row)
+};
+struct GemmTable {
+    GemmDesc g[MAX_GEMMS];
+    int n;
+};
+
+__device__ __forceinline__ int64_t slice_stride(const GemmDesc &g) {
+    return (int64_t)g.a_width * g.x_width + SLICE_EXTRA;
+}
+
+template <int NA, int KB>
+__device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const float *__restrict__ saved,
+                                        const float *__restrict__ dy, float *__restrict__ partial, int64_t MP,
+                                        char *lds, int tid, int lane, int wave) {
+    constexpr int AW = 128 * NA;  // a_width: each of the 4 waves owns 32*NA rows
+    constexpr int XW = 32 * KB;
+    constexpr int A_PIECES = 32 * AW * 4 / 1024 / 4;  // 1-KiB DMA pieces per wave
+    constexpr int X_PIECES = 32 * XW * 4 / 1024;      // pieces for the whole X tile (may be < 4)
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t tiles_total = MP / 32;
+    const int64_t t0 = tiles_total * slice / g.num_slices;
+    const int64_t t1 = tiles_total * (slice + 1) / g.num_slices;
+    const char *a_src = reinterpret_cast<const char *>(dy + g.a_off);
+    const char *x_src = reinterpret_cast<const char *>(saved + g.x_off);
+    const float *dsig = dy + dsig_plane(MP);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+
+    f32x16 acc[NA][KB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float bias_acc = 0.0f, dens_acc = 0.0f, dens_b = 0.0f;
+
+    auto issue = [&](int64_t t, int buf) {
+        const char *as = a_src + t * (32 * AW * 4) + lane * 16;
+        const unsigned ad = lds_base + buf * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < A_PIECES; ++j) {
+            const int p = wave + 4 * j;
+            lds_dma_16(as + p * 1024, ad + p * 1024);
+        }
+        const char *xs = x_src + t * (32 * XW * 4) + lane * 16;
+        const unsigned xd = lds_base + buf * STAGE_BYTES + 32768;
+#pragma unroll
+        for (int j = 0; j < (X_PIECES + 3) / 4; ++j) {
+            const int p = wave + 4 * j;
+            if (p < X_PIECES) lds_dma_16(xs + p * 1024, xd + p * 1024);
+        }
+    };
+
+    if (t0 < t1) issue(t0, 0);
+    for (int64_t t = t0; t < t1; ++t) {
+        const int buf = (int)((t - t0) & 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < t1) issue(t + 1, buf ^ 1);
+        const float *A = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES);
+        const float *X = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES + 32768);
+        // side jobs on the vector ALU: column sums of dY (bias) and the density row of fc_8
+        if ((g.flags & FLAG_BIAS) && tid < AW) {
+            float s = 0.0f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) s += A[r * AW + tid];
+            bias_acc += s;
+        }
+        if (g.flags & FLAG_DENSITY) {
+            float s = 0.0f, sb = 0.0f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const float ds = dsig[t * 32 + r];
+                sb += ds;
+                if (tid < XW) s = fmaf(ds, X[r * XW + tid], s);
+            }
+            dens_acc += s;
+            dens_b += sb;
+        }
+        // dW += dY^T X over the 32 samples of the tile: 16 k-steps of 2 samples
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            float a[NA], b[KB];
+#pragma unroll
+            for (int nb = 0; nb < NA; ++nb) a[nb] = A[(2 * s + h) * AW + wave * 32 * NA + 32 * nb + i];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) b[kb] = X[(2 * s + h) * XW + 32 * kb + i];
+#pragma unroll
+            for (int nb = 0; nb < NA; ++nb)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], b[kb], acc[nb][kb], 0, 0, 0);
+        }
+    }
+    // partial tile of this slice: row-major [AW][XW], then bias[AW], then density row [XW] + its bias
+    float *out = partial + g.partial_off + slice * slice_stride(g);
+#pragma unroll
+    for (int nb = 0; nb < NA; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = wave * 32 * NA + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[n * XW + 32 * kb + i] = acc[nb][kb][r];
+            }
+    float *extra = out + AW * XW;
+    if ((g.flags & FLAG_BIAS) && tid < AW) extra[tid] = bias_acc;
+    if (g.flags & FLAG_DENSITY) {
+        if (tid < XW) extra[256 + tid] = dens_acc;
+        if (tid == 0) extra[256 + XW] = dens_b;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, const float *__restrict__ saved,
+                                                             const float *__restrict__ dy,
+                                                             float *__restrict__ partial, int64_t M) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t MP = padded_rows(M);
+    int gi = 0;
+    for (int k = 1; k < table.n; ++k)
+        if ((int)blockIdx.x >= table.g[k].first_block) gi = k;
+    const GemmDesc &g = table.g[gi];
+    const int slice = (int)blockIdx.x - g.first_block;
+    if (slice >= g.num_slices) return;
+    if (g.a_width == 256 && g.x_width == 256) dw_body<2, 8>(g, slice, saved, dy, partial, MP, lds, tid, lane, wave);
+    else if (g.a_width == 256 && g.x_width == 64) dw_body<2, 2>(g, slice, saved, dy, partial, MP, lds, tid, lane, wave);
+    else if (g.a_width == 128 && g.x_width == 256) dw_body<1, 8>(g, slice, saved, dy, partial, MP, lds, tid, lane, wave);
+    else dw_body<1, 1>(g, slice, saved, dy, partial, MP, lds, tid, lane, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// fc_out (3 x 128) and its bias on the vector ALU: block b sums samples [b*chunk, (b+1)*chunk)
+constexpr int OUT_BLOCKS = 256;
+constexpr int OUT_STRIDE = 512;  // 3*128 weights + 3 biases, padded
+__global__ __launch_bounds__(128) void mlp_bwd_out_kernel(const float *__restrict__ saved,
+                                                          const float *__restrict__ rgb,
+                                                          const float *__restrict__ g_rgb, int64_t M,
+                                                          float *__restrict__ partial_out) {
+    const int64_t MP = padded_rows(M);
+    const float *h9 = saved + pl_h9(MP);
+    const int k = threadIdx.x;
+    const int64_t chunk = (M + OUT_BLOCKS - 1) / OUT_BLOCKS;
+    const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (int64_t m = lo; m < hi; ++m) {
+        const float y0 = rgb[3 * m], y1 = rgb[3 * m + 1], y2 = rgb[3 * m + 2];
+        const float gy0 = g_rgb[3 * m] * y0 * (1.0f - y0);
+        const float gy1 = g_rgb[3 * m + 1] * y1 * (1.0f - y1);
+        const float gy2 = g_rgb[3 * m + 2] * y2 * (1.0f - y2);
+        const float x = h9[m * HALF + k];
+        w0 = fmaf(gy0, x, w0);
+        w1 = fmaf(gy1, x, w1);
+        w2 = fmaf(gy2, x, w2);
+        b0 += gy0; b1 += gy1; b2 += gy2;
+    }
+    float *out = partial_out + (int64_t)blockIdx.x * OUT_STRIDE;
+    out[k] = w0;
+    out[HALF + k] = w1;
+    out[2 * HALF + k] = w2;
+    if (k == 0) { out[384] = b0; out[385] = b1; out[386] = b2; }
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 3: reduce partial tiles into the flat gradient (state_dict layout), fixed order
+// ------------------------------------------------------------------------------------------
+__global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__ partial,
+                                      const float *__restrict__ partial_out, float *__restrict__ g_params) {
+    const int gi = blockIdx.y;
+    const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    if (gi == table.n) {  // fc_out
+        for (int64_t e = e0; e < 3 * HALF + 3; e += step) {
+            float s = 0.0f;
+            for (int b = 0; b < OUT_BLOCKS; ++b) s += partial_out[(int64_t)b * OUT_STRIDE + e];
+            g_params[w_offset(10) + e] = s;  // weight (3,128) then bias (3): contiguous in the blob
+        }
+        return;
+    }
+    const GemmDesc &g = table.g[gi];
+    const float *base = partial + g.partial_off;
+    const int64_t stride = slice_stride(g);
+    const int64_t tile = (int64_t)g.a_width * g.valid_cols;
+    const int64_t total = tile + ((g.flags & FLAG_BIAS) ? g.a_width : 0) +
+                          ((g.flags & FLAG_DENSITY) ? g.x_width + 1 : 0);
+    for (int64_t e = e0; e < total; e += step) {
+        int64_t src, dst;
+        if (e < tile) {
+            const int n = (int)(e / g.valid_cols), k = (int)(e % g.valid_cols);
+            src = (int64_t)n * g.x_width + k;
+            dst = g.w_off + (int64_t)(n + g.row0) * g.in_features + g.col0 + k;
+        } else if ((g.flags & FLAG_BIAS) && e < tile + g.a_width) {
+            const int n = (int)(e - tile);
+            src = (int64_t)g.a_width * g.x_width + n;
+            dst = g.b_off + g.row0 + n;
+        } else {
+            const int k = (int)(e - tile - ((g.flags & FLAG_BIAS) ? g.a_width : 0));
+            src = (int64_t)g.a_width * g.x_width + 256 + k;
+            dst = k < g.x_width ? g.w_off + k : g.b_off;  // density row 0 of fc_8, then fc_8.bias[0]
+        }
+        float s = 0.0f;
+        for (int sl = 0; sl < g.num_slices; ++sl) s += base[sl * stride + src];
+        g_params[dst] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct Plan {
+    GemmTable table;
+    int total_blocks;
+    int64_t partial_floats;
+};
+
+Plan make_plan(int64_t M, int cus) {
+    const int64_t MP = padded_rows(M);
+    const int64_t tiles = MP / 32;
+    Plan p;
+    GemmTable &T = p.table;
+    int n = 0;
+    auto add = [&](int layer, int64_t a_off, int a_width, int64_t x_off, int x_width, int col0, int valid_cols,
+                   int row0, int flags) {
+        GemmDesc &g = T.g[n++];
+        g.a_off = a_off; g.x_off = x_off; g.a_width = a_width; g.x_width = x_width;
+        g.flags = flags; g.in_features = DIMS[layer].in; g.col0 = col0; g.valid_cols = valid_cols; g.row0 = row0;
+        g.w_off = w_offset(layer); g.b_off = b_offset(layer);
+    };
+    add(0, dy_plane(MP, 0), 256, pl_pe(MP), 64, 0, E_POS, 0, FLAG_BIAS);
+    for (int l = 1; l <= 4; ++l) add(l, dy_plane(MP, l), 256, pl_h(MP, l - 1), 256, 0, 256, 0, FLAG_BIAS);
+    add(5, dy_plane(MP, 5), 256, pl_pe(MP), 64, 0, E_POS, 0, 0);
+    add(5, dy_plane(MP, 5), 256, pl_h(MP, 4), 256, E_POS, 256, 0, FLAG_BIAS);
+    add(6, dy_plane(MP, 6), 256, pl_h(MP, 5), 256, 0, 256, 0, FLAG_BIAS);
+    add(7, dy_plane(MP, 7), 256, pl_h(MP, 6), 256, 0, 256, 0, FLAG_BIAS);
+    add(8, dy_plane(MP, 8), 256, pl_h(MP, 7), 256, 0, 256, 1, FLAG_BIAS | FLAG_DENSITY);
+    add(9, dy9_plane(MP), 128, pl_y8(MP), 256, 0, 256, 0, FLAG_BIAS);
+    add(9, dy9_plane(MP), 128, pl_de(MP), 32, FEAT, E_DIR, 0, 0);
+    T.n = n;
+    // slices proportional to MFMA work per tile, one workgroup per CU in total
+    int64_t cost[MAX_GEMMS], cost_sum = 0;
+    for (int k = 0; k < n; ++k) {
+        cost[k] = (int64_t)(T.g[k].a_width / 128) * (T.g[k].x_width / 32);
+        cost_sum += cost[k];
+    }
+    int block = 0;
+    int64_t off = 0;
+    for (int k = 0; k < n; ++k) {
+        int64_t s = (int64_t)cus * cost[k] / cost_sum;
+        if (s < 1) s = 1;
+        if (s > tiles) s = tiles;
+        T.g[k].first_block = block;
+        T.g[k].num_slices = (int)s;
+        T.g[k].partial_off = off;
+        block += (int)s;
+        off += s * ((int64_t)T.g[k].a_width * T.g[k].x_width + SLICE_EXTRA);
+    }
+    p.total_blocks = block;
+    p.partial_floats = off;
+    return p;
+}
+
+int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+inline int64_t align256f(int64_t floats) { return (floats + 63) & ~(int64_t)63; }
+
+}  // namespace
+
+NERF_API int64_t nerf_mlp_backward_workspace_bytes(int64_t M) {
+    if (M <= 0) return 0;
+    const int64_t MP = mlp::padded_rows(M);
+    // upper bound on the partial buffer that does not depend on the device: 2 x 256 slices of a full tile
+    const int64_t partial = (int64_t)(2 * 256 + MAX_GEMMS) * (256 * 256 + SLICE_EXTRA);
+    return 4 * (align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE) + partial + (int64_t)OUT_BLOCKS * OUT_STRIDE);
+}
+
+NERF_API int nerf_mlp_backward(const void *packed, const float *params, const float *pos,
+                               const float *view_dir, int64_t M, int encoded, const float *sigma,
+                               const float *rgb, const void *saved, const float *g_sigma, const float *g_rgb,
+                               float *g_params, void *workspace, nerf_stream_t stream) {
+    (void)params; (void)pos; (void)view_dir; (void)encoded;  // the saved record holds the encodings
+    NERF_REQUIRE(M >= 0, "nerf_mlp_backward: negative M");
+    NERF_REQUIRE(g_params, "nerf_mlp_backward: null g_params");
+    hipStream_t s = nerf::as_stream(stream);
+    if (M == 0) {
+        if (hipMemsetAsync(g_params, 0, sizeof(float) * mlp::PARAM_COUNT, s) != hipSuccess)
+            return nerf::check_launch("nerf_mlp_backward: memset");
+        return NERF_OK;
+    }
+    NERF_REQUIRE(packed && sigma && rgb && saved && g_sigma && g_rgb && workspace,
+                 "nerf_mlp_backward: null pointer");
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_dx_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, mlp::LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_dw_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES) != hipSuccess)
+            return nerf::check_launch("nerf_mlp_backward: LDS attribute");
+        configured = true;
+    }
+    const int cus = device_cus();
+    const int64_t MP = mlp::padded_rows(M);
+    float *dy = static_cast<float *>(workspace);
+    float *partial = dy + align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE);
+    const Plan plan = make_plan(M, cus);
+    float *partial_out = partial + plan.partial_floats;
+    const float *sv = static_cast<const float *>(saved);
+
+    const int64_t ntiles = MP / mlp::TILE_SAMPLES;
+    hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(256),
+                       mlp::LDS_BYTES, s, static_cast<const char *>(packed), M, sigma, rgb, g_sigma, g_rgb, sv,
+                       dy);
+    int rc = nerf::check_launch("nerf_mlp_backward: dx chain");
+    if (rc != NERF_OK) return rc;
+    hipLaunchKernelGGL(mlp_bwd_dw_kernel, dim3((unsigned)plan.total_blocks), dim3(256), DW_LDS_BYTES, s,
+                       plan.table, sv, static_cast<const float *>(dy), partial, M);
+    rc = nerf::check_launch("nerf_mlp_backward: dW");
+    if (rc != NERF_OK) return rc;
+    hipLaunchKernelGGL(mlp_bwd_out_kernel, dim3(OUT_BLOCKS), dim3(128), 0, s, sv, rgb, g_rgb, M, partial_out);
+    rc = nerf::check_launch("nerf_mlp_backward: fc_out");
+    if (rc != NERF_OK) return rc;
+    hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(64, plan.table.n + 1), dim3(256), 0, s, plan.table,
+                       static_cast<const float *>(partial), static_cast<const float *>(partial_out), g_params);
+    return nerf::check_launch("nerf_mlp_backward: reduce");
 }

@@ -1,0 +1,176 @@
+// Device-side building blocks shared by the fused MLP kernels (forward, backward dX chain, dW).
+// See mlp_layout.h for the fragment algebra and the packed stream these operate on.
+#pragma once
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace mlp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// sin and cos with a 3-term Cody-Waite reduction (FMA) and Cephes minimax polynomials:
+// <= ~1.5e-7 abs error for |x| < 3e4; larger arguments take the library path.
+__device__ __forceinline__ void sincos_cw(float x, float &s, float &c) {
+    if (__builtin_expect(fabsf(x) > 30000.0f, 0)) {
+        s = sinf(x);
+        c = cosf(x);
+        return;
+    }
+    const float n = rintf(x * 0.636619747f);
+    float r = fmaf(-n, 1.57079637e+0f, x);
+    r = fmaf(-n, -4.37113883e-8f, r);
+    r = fmaf(-n, -1.71512451e-15f, r);
+    const int q = (int)n;
+    const float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    sp = fmaf(sp * r2, r, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    cp = fmaf(cp * r2, r2, fmaf(r2, -0.5f, 1.0f));
+    const float ss = (q & 1) ? cp : sp;
+    const float cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// feature k of PositionalEncoder(3, L, include_input=True).encode((x,y,z)); 0 beyond kmax
+// layout (positional_encoder.py:83-88): [x y z | sin(2^0 xyz) cos(2^0 xyz) | sin(2^1 xyz) ...]
+__device__ __forceinline__ float enc_feature(int k, float x, float y, float z, int kmax) {
+    const int e = k - 3;
+    const int f = e / 6;
+    const int r6 = e - 6 * f;
+    const int ch = k < 3 ? k : (r6 >= 3 ? r6 - 3 : r6);
+    const float v = ch == 0 ? x : (ch == 1 ? y : z);
+    float s, c;
+    sincos_cw(ldexpf(v, f < 0 ? 0 : f), s, c);
+    const float t = r6 >= 3 ? c : s;
+    return k < 3 ? v : (k < kmax ? t : 0.0f);
+}
+
+// one 1-KiB piece per instruction: LDS[m0 + lane*16] <- global[src]
+__device__ __forceinline__ void lds_dma_16(const char *src, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_dst)
+        : "memory");
+}
+
+struct Pipe {
+    const char *src_lane;  // stream base + this lane's byte offset inside a chunk
+    unsigned lds_wave;     // LDS byte address of ring slot 0 + this wave's offset
+    unsigned issued;       // chunks issued so far
+    int issue_pos;         // stream position (0..n_chunks-1) of the next chunk to issue
+    unsigned consumed;     // chunks consumed so far
+    int n_chunks;
+
+    __device__ __forceinline__ void issue() {
+        const char *s = src_lane + (size_t)issue_pos * CHUNK_BYTES;
+        const unsigned d = lds_wave + (issued & (RING_SLOTS - 1)) * CHUNK_BYTES;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds_dma_16(s + j * 1024, d + j * 1024);
+        ++issued;
+        issue_pos = (issue_pos + 1 == n_chunks) ? 0 : issue_pos + 1;
+    }
+    // make the next chunk readable; returns the LDS byte offset (from slot 0) of its image
+    __device__ __forceinline__ unsigned acquire() {
+        // three chunks (3 x 8 DMA instructions of this wave) are in flight: the oldest must land
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's pieces landed; everyone left the slot refilled next
+        asm volatile("" ::: "memory");
+        issue();
+        const unsigned slot = consumed & (RING_SLOTS - 1);
+        ++consumed;
+        return slot * CHUNK_BYTES;
+    }
+};
+
+template <int NFB>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, const char *chunk,
+                                          const int (&offq)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(chunk + fb * 4096 + offq[q]);
+            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * q + 0], acc[fb], 0, 0, 0);
+            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * q + 1], acc[fb], 0, 0, 0);
+            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * q + 2], acc[fb], 0, 0, 0);
+            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * q + 3], acc[fb], 0, 0, 0);
+        }
+    }
+}
+
+// acc[fb][4q..4q+3] <- bias[32 fb + 8 q + 4 h ..]: the C fragment starts as the bias
+template <int NFB>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[8], const float *bias, int h) {
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(bias + 32 * fb + 8 * q + 4 * h);
+            acc[fb][4 * q + 0] = v.x;
+            acc[fb][4 * q + 1] = v.y;
+            acc[fb][4 * q + 2] = v.z;
+            acc[fb][4 * q + 3] = v.w;
+        }
+}
+
+// row m of a row-major plane <- this lane's 4-feature groups; rows beyond M are written as zeros
+template <int NFB>
+__device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, bool valid, int h,
+                                           const f32x16 *blk) {
+    float *row = plane + m * width + 4 * h;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
+            if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(row + 32 * fb + 8 * q) = v;
+        }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ReLU sign bits of a layer: dword fb>>1, bit 16*(fb&1)+r  <-  blk[fb][r] > 0
+template <int NFB>
+__device__ __forceinline__ void save_mask(float *mask_plane, int64_t m, bool valid, int h, const f32x16 *blk) {
+    u32x4 bits = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+        unsigned w = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w |= (blk[fb][r] > 0.0f ? 1u : 0u) << r;
+        bits[fb >> 1] |= w << (16 * (fb & 1));
+    }
+    if (!valid) bits = u32x4{0u, 0u, 0u, 0u};
+    reinterpret_cast<u32x4 *>(mask_plane)[2 * m + h] = bits;
+}
+
+// sum over this lane's half of the features of w[feature] * x[feature]; w in LDS
+template <int NFB>
+__device__ __forceinline__ float half_dot(const float *w, const f32x16 *x, int h) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(w + 32 * fb + 8 * q + 4 * h);
+            s0 = fmaf(v.x, x[fb][4 * q + 0], s0);
+            s1 = fmaf(v.y, x[fb][4 * q + 1], s1);
+            s2 = fmaf(v.z, x[fb][4 * q + 2], s2);
+            s3 = fmaf(v.w, x[fb][4 * q + 3], s3);
+        }
+    return (s0 + s1) + (s2 + s3);
+}
+
+
+}  // namespace mlp

@@ -79,14 +79,39 @@ constexpr int64_t PACKED_BYTES = FWD_BYTES + (int64_t)BWD_CHUNKS * CHUNK_BYTES;
 constexpr int RING_SLOTS = 4;
 constexpr int LDS_BYTES = RING_SLOTS * CHUNK_BYTES + CONST_BYTES;  // 144384 <= 160 KiB
 
-// ---- activation record written by the training-mode forward (row-major planes)
-//   plane 0      : encoded position, 64 floats/sample (63 + one zero)
-//   planes 1..8  : post-ReLU outputs of fc_in, fc_1 .. fc_7, 256 floats/sample
-//   plane 9      : fc_8 output rows 1..256 (no ReLU), 256 floats/sample
-//   plane 10     : post-ReLU fc_9 output, 128 floats/sample
-//   plane 11     : encoded direction, 32 floats/sample (27 + zeros)
+// ---- activation record written by the training-mode forward.  All planes are row-major
+// with MP = M rounded up to a multiple of 128 rows; rows >= M are written as zeros so that the
+// backward GEMMs may consume whole 32-row tiles.
+//   float planes (offsets in floats, x MP):
+//     PL_PE   : encoded position, 64 floats/sample (63 + one zero)
+//     PL_H(l) : post-ReLU outputs of fc_in (l=0), fc_1 .. fc_7 (l=7), 256 floats/sample
+//     PL_Y8   : fc_8 output rows 1..256 (no ReLU), 256 floats/sample
+//     PL_H9   : post-ReLU fc_9 output, 128 floats/sample
+//     PL_DE   : encoded direction, 32 floats/sample (27 + zeros)
+//   mask planes (after the float planes): 9 planes (h0..h7, h9) of 32 B/sample: for sample m and
+//   lane half h, a uint4 at index 2m+h whose dword fb>>1, bit 16*(fb&1)+r is (activation > 0)
+//   for the D-fragment register r of feature block fb.
 constexpr int SAVED_FLOATS_PER_SAMPLE = 64 + 8 * 256 + 256 + 128 + 32;  // 2528
+constexpr int SAVED_MASK_PLANES = 9;
+constexpr int SAVED_BYTES_PER_SAMPLE = SAVED_FLOATS_PER_SAMPLE * 4 + SAVED_MASK_PLANES * 32;  // 10400
 constexpr int TILE_SAMPLES = 128;  // one workgroup pass: 4 wavefronts x 32 samples
+__host__ __device__ constexpr int64_t padded_rows(int64_t M) { return (M + TILE_SAMPLES - 1) / TILE_SAMPLES * TILE_SAMPLES; }
+__host__ __device__ constexpr int64_t pl_pe(int64_t MP) { return 0; }
+__host__ __device__ constexpr int64_t pl_h(int64_t MP, int l) { return MP * (64 + 256 * (int64_t)l); }
+__host__ __device__ constexpr int64_t pl_y8(int64_t MP) { return MP * (64 + 256 * 8); }
+__host__ __device__ constexpr int64_t pl_h9(int64_t MP) { return MP * (64 + 256 * 9); }
+__host__ __device__ constexpr int64_t pl_de(int64_t MP) { return MP * (64 + 256 * 9 + 128); }
+__host__ __device__ constexpr int64_t pl_masks(int64_t MP) { return MP * SAVED_FLOATS_PER_SAMPLE; }  // in floats
+
+// ---- gradient planes written by the backward dX chain (workspace, offsets in floats, x MP):
+//   DY(l), l = 0..7 : grad w.r.t. the pre-activation of fc_in, fc_1 .. fc_7 (256/sample)
+//   DY8             : grad w.r.t. fc_8 output rows 1..256                    (256/sample)
+//   DY9             : grad w.r.t. the pre-activation of fc_9                 (128/sample)
+//   DSIG            : grad w.r.t. fc_8 output row 0 (density pre-activation) (1/sample)
+__host__ __device__ constexpr int64_t dy_plane(int64_t MP, int l) { return MP * 256 * (int64_t)l; }  // l = 0..8
+__host__ __device__ constexpr int64_t dy9_plane(int64_t MP) { return MP * 256 * 9; }
+__host__ __device__ constexpr int64_t dsig_plane(int64_t MP) { return MP * (256 * 9 + 128); }
+constexpr int DY_FLOATS_PER_SAMPLE = 256 * 9 + 128 + 1;
 
 // physical byte offset, inside a chunk image, of the 16-byte slot holding
 // W[row n][k-group c] (c = (k % 32) / 4)
