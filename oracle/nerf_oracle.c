@@ -408,19 +408,20 @@ ORC_API void orc_mlp_forward(const float *params, int E_p, int E_d, int F, const
 
 /* ------------------------------------------------------------------ */
 /* a13 (MLP part): parameter gradients for upstream (g_sigma (M,),     */
-/* g_rgb (M,3)).  Hand-derived reverse of nerf.py:102-119; per-thread  */
-/* fp32 accumulators are reduced in fp64 at the end (the reference's   */
-/* autograd sums in fp32 through sgemm: a tolerance quantity).         */
+/* g_rgb (M,3)).  Hand-derived reverse of nerf.py:102-119.  Sums over   */
+/* samples run in double (the reference's autograd sums in fp32 inside */
+/* sgemm: a tolerance quantity; the oracle is the yardstick).          */
 /* ------------------------------------------------------------------ */
 static void linear_bwd(const float *W, int in, int out, const float *x, const float *gy,
-                       float *gW, float *gb, float *gx /* may be NULL */, int gx_from, int gx_n)
+                       double *gW, double *gb, float *gx /* may be NULL */, int gx_from, int gx_n)
 {
+    /* parameter gradients accumulate in double: the oracle is the yardstick */
     for (int n = 0; n < out; ++n) {
-        const float g = gy[n];
-        if (g == 0.0f) continue;
-        float *gw = gW + (int64_t)n * in;
-        for (int k = 0; k < in; ++k) gw[k] = gw[k] + g * x[k];
-        gb[n] = gb[n] + g;
+        const double g = (double)gy[n];
+        if (g == 0.0) continue;
+        double *gw = gW + (int64_t)n * in;
+        for (int k = 0; k < in; ++k) gw[k] += g * (double)x[k];
+        gb[n] += g;
     }
     if (gx) {
         for (int k = 0; k < gx_n; ++k) {
@@ -442,14 +443,14 @@ ORC_API void orc_mlp_backward(const float *params, int E_p, int E_d, int F, cons
 #if defined(_OPENMP)
     nthreads = omp_get_max_threads();
 #endif
-    float **local = (float **)calloc((size_t)nthreads, sizeof(float *));
+    double **local = (double **)calloc((size_t)nthreads, sizeof(double *));
 #pragma omp parallel
     {
         int tid = 0;
 #if defined(_OPENMP)
         tid = omp_get_thread_num();
 #endif
-        float *G = (float *)calloc((size_t)total, sizeof(float));
+        double *G = (double *)calloc((size_t)total, sizeof(double));
         local[tid] = G;
         act_t A; act_alloc(&A, E_p, F);
         float *cat5 = (float *)malloc(sizeof(float) * (F + E_p));
@@ -501,7 +502,7 @@ ORC_API void orc_mlp_backward(const float *params, int E_p, int E_d, int F, cons
     for (int64_t i = 0; i < total; ++i) {
         double s = 0.0;
         for (int t = 0; t < nthreads; ++t)
-            if (local[t]) s += (double)local[t][i];
+            if (local[t]) s += local[t][i];
         g_params[i] = (float)((double)g_params[i] + s);
     }
     for (int t = 0; t < nthreads; ++t) free(local[t]);

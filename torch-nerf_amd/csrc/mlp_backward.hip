@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
                     }
                 }
         }
-        save_plane<4>(dy + dy9_plane(MP), 128, m, valid, h, act);
+        save_plane<4>(dy + dy9_plane(MP), 128, m, h, act);
 
         // ---- d y8[1:257] = W9[:, 0:256]^T dY9   (fc_9 input is cat([x[:,1:], dir]): nerf.py:116)
 #pragma unroll
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         for (int kb = 0; kb < 4; ++kb) mma_chunk<8>(acc, act[kb], lds + pipe.acquire(), offq);
 #pragma unroll
         for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];  // fc_8 has no ReLU
-        save_plane<8>(dy + dy_plane(MP, 8), 256, m, valid, h, act);
+        save_plane<8>(dy + dy_plane(MP, 8), 256, m, h, act);
         if (h == 0) dy[dsig_plane(MP) + m] = dsig;
 
         // ---- l = 8 .. 1:  dY(l-1) = (W_l^T dY(l)) . [h(l-1) > 0]
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
             for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) act[fb][r] = mask_bit(mk, fb, r) ? acc[fb][r] : 0.0f;
-            save_plane<8>(dy + dy_plane(MP, l - 1), 256, m, valid, h, act);
+            save_plane<8>(dy + dy_plane(MP, l - 1), 256, m, h, act);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -149,8 +149,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_GEMMS = 13;
 constexpr int SLICE_EXTRA = 1024;  // floats reserved after each partial tile: bias (<=256) + density row (<=257)
-constexpr int STAGE_BYTES = 65536;  // A tile (<= 32 KiB) + X tile (<= 32 KiB)
-constexpr int DW_LDS_BYTES = 2 * STAGE_BYTES;
+constexpr int DW_LDS_BYTES = 131072;  // 2 stages of 64 KiB (wide X) or 3 stages of 40 KiB (thin X)
 enum { FLAG_BIAS = 1, FLAG_DENSITY = 2 };
 
 struct GemmDesc {
@@ -176,6 +175,15 @@ __device__ __forceinline__ int64_t slice_stride(const GemmDesc &g) {
     return (int64_t)g.a_width * g.x_width + SLICE_EXTRA;
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 3 || N == 5 || N == 10, "add the immediate below");
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    if (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    if (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+}
+
 template <int NA, int KB>
 __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const float *__restrict__ saved,
                                         const float *__restrict__ dy, float *__restrict__ partial, int64_t MP,
@@ -183,7 +191,13 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
     constexpr int AW = 128 * NA;  // a_width: each of the 4 waves owns 32*NA rows
     constexpr int XW = 32 * KB;
     constexpr int A_PIECES = 32 * AW * 4 / 1024 / 4;  // 1-KiB DMA pieces per wave
-    constexpr int X_PIECES = 32 * XW * 4 / 1024;      // pieces for the whole X tile (may be < 4)
+    constexpr int X_PIECES = 32 * XW * 4 / 1024;      // pieces for the whole X tile (4 | 8 | 32)
+    constexpr int A_BYTES = 32 * AW * 4, X_BYTES = 32 * XW * 4;
+    constexpr int STAGE_BYTES = A_BYTES + X_BYTES;
+    // thin X tiles finish their MFMAs faster than one DMA round trip: keep two tiles in flight
+    constexpr int NSTAGE = (KB <= 2) ? 3 : 2;
+    static_assert(NSTAGE * STAGE_BYTES <= DW_LDS_BYTES, "stage ring exceeds the LDS allocation");
+    constexpr int PER_WAVE = A_PIECES + X_PIECES / 4;  // DMA instructions per wave per tile
     const int i = lane & 31, h = lane >> 5;
     const int64_t tiles_total = MP / 32;
     const int64_t t0 = tiles_total * slice / g.num_slices;
@@ -211,7 +225,7 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
             lds_dma_16(as + p * 1024, ad + p * 1024);
         }
         const char *xs = x_src + t * (32 * XW * 4) + lane * 16;
-        const unsigned xd = lds_base + buf * STAGE_BYTES + 32768;
+        const unsigned xd = lds_base + buf * STAGE_BYTES + A_BYTES;
 #pragma unroll
         for (int j = 0; j < (X_PIECES + 3) / 4; ++j) {
             const int p = wave + 4 * j;
@@ -219,15 +233,22 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
         }
     };
 
-    if (t0 < t1) issue(t0, 0);
+    // prologue: NSTAGE-1 tiles in flight (tiles past the end are re-reads of the last tile: the
+    // instruction count per step stays fixed so the counted wait below is exact)
+    for (int d = 0; d < NSTAGE - 1; ++d) issue(t0 + d < t1 ? t0 + d : t1 - 1, d);
+    int buf = 0;
     for (int64_t t = t0; t < t1; ++t) {
-        const int buf = (int)((t - t0) & 1);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        wait_vmcnt<(NSTAGE - 2) * PER_WAVE>();   // tile t landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();            // ... and everybody else's; stage (t-1) is free again
         asm volatile("" ::: "memory");
-        if (t + 1 < t1) issue(t + 1, buf ^ 1);
+        {
+            const int64_t tn = t + NSTAGE - 1;
+            int nb = buf + NSTAGE - 1;
+            if (nb >= NSTAGE) nb -= NSTAGE;
+            issue(tn < t1 ? tn : t1 - 1, nb);
+        }
         const float *A = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES);
-        const float *X = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES + 32768);
+        const float *X = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES + A_BYTES);
         // side jobs on the vector ALU: column sums of dY (bias) and the density row of fc_8
         if ((g.flags & FLAG_BIAS) && tid < AW) {
             float s = 0.0f;
@@ -260,6 +281,7 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
                 for (int kb = 0; kb < KB; ++kb)
                     acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], b[kb], acc[nb][kb], 0, 0, 0);
         }
+        buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     }
     // partial tile of this slice: row-major [AW][XW], then bias[AW], then density row [XW] + its bias
     float *out = partial + g.partial_off + slice * slice_stride(g);
@@ -301,35 +323,59 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// fc_out (3 x 128) and its bias on the vector ALU: block b sums samples [b*chunk, (b+1)*chunk)
-constexpr int OUT_BLOCKS = 256;
+// fc_out (3 x 128) and its bias on the vector ALU: block b sums samples [b*chunk, (b+1)*chunk);
+// 4 groups of 128 threads take every 4th sample, 2 samples in flight each, combined through LDS.
+constexpr int OUT_BLOCKS = 512;
 constexpr int OUT_STRIDE = 512;  // 3*128 weights + 3 biases, padded
-__global__ __launch_bounds__(128) void mlp_bwd_out_kernel(const float *__restrict__ saved,
+__global__ __launch_bounds__(512) void mlp_bwd_out_kernel(const float *__restrict__ saved,
                                                           const float *__restrict__ rgb,
                                                           const float *__restrict__ g_rgb, int64_t M,
                                                           float *__restrict__ partial_out) {
+    __shared__ float red[4][3 * HALF + 4];
     const int64_t MP = padded_rows(M);
     const float *h9 = saved + pl_h9(MP);
-    const int k = threadIdx.x;
+    const int k = threadIdx.x & (HALF - 1), grp = threadIdx.x >> 7;
     const int64_t chunk = (M + OUT_BLOCKS - 1) / OUT_BLOCKS;
     const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
-    float w0 = 0.f, w1 = 0.f, w2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-    for (int64_t m = lo; m < hi; ++m) {
-        const float y0 = rgb[3 * m], y1 = rgb[3 * m + 1], y2 = rgb[3 * m + 2];
-        const float gy0 = g_rgb[3 * m] * y0 * (1.0f - y0);
-        const float gy1 = g_rgb[3 * m + 1] * y1 * (1.0f - y1);
-        const float gy2 = g_rgb[3 * m + 2] * y2 * (1.0f - y2);
-        const float x = h9[m * HALF + k];
-        w0 = fmaf(gy0, x, w0);
-        w1 = fmaf(gy1, x, w1);
-        w2 = fmaf(gy2, x, w2);
-        b0 += gy0; b1 += gy1; b2 += gy2;
+    float w[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
+    float w2[3] = {0.f, 0.f, 0.f}, b2[3] = {0.f, 0.f, 0.f};
+    auto grad = [&](int64_t m, float (&gy)[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float y = rgb[3 * m + c];
+            gy[c] = g_rgb[3 * m + c] * y * (1.0f - y);
+        }
+    };
+    int64_t m = lo + grp;
+    for (; m + 4 < hi; m += 8) {
+        float ga[3], gb[3];
+        grad(m, ga);
+        grad(m + 4, gb);
+        const float xa = h9[m * HALF + k], xb = h9[(m + 4) * HALF + k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            w[c] = fmaf(ga[c], xa, w[c]);
+            w2[c] = fmaf(gb[c], xb, w2[c]);
+            b[c] += ga[c];
+            b2[c] += gb[c];
+        }
     }
+    for (; m < hi; m += 4) {
+        float ga[3];
+        grad(m, ga);
+        const float xa = h9[m * HALF + k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { w[c] = fmaf(ga[c], xa, w[c]); b[c] += ga[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        red[grp][c * HALF + k] = w[c] + w2[c];
+        if (k == 0) red[grp][3 * HALF + c] = b[c] + b2[c];
+    }
+    __syncthreads();
     float *out = partial_out + (int64_t)blockIdx.x * OUT_STRIDE;
-    out[k] = w0;
-    out[HALF + k] = w1;
-    out[2 * HALF + k] = w2;
-    if (k == 0) { out[384] = b0; out[385] = b1; out[386] = b2; }
+    for (int e = threadIdx.x; e < 3 * HALF + 3; e += 512)
+        out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -407,16 +453,20 @@ Plan make_plan(int64_t M, int cus) {
     add(9, dy9_plane(MP), 128, pl_y8(MP), 256, 0, 256, 0, FLAG_BIAS);
     add(9, dy9_plane(MP), 128, pl_de(MP), 32, FEAT, E_DIR, 0, 0);
     T.n = n;
-    // slices proportional to MFMA work per tile, one workgroup per CU in total
-    int64_t cost[MAX_GEMMS], cost_sum = 0;
+    // Slices proportional to the time one 32-row tile costs a workgroup, one workgroup per CU in
+    // total: max(MFMA time, tile bytes at ~20 GB/s of LDS-DMA per CU, ~1 us of round-trip floor).
+    double cost[MAX_GEMMS], cost_sum = 0;
     for (int k = 0; k < n; ++k) {
-        cost[k] = (int64_t)(T.g[k].a_width / 128) * (T.g[k].x_width / 32);
+        const double mfma_us = (T.g[k].a_width / 128) * (T.g[k].x_width / 32) * 16 * 64 / 2400.0;
+        const double dma_us = 32.0 * 4 * (T.g[k].a_width + T.g[k].x_width) / 20e3;
+        cost[k] = mfma_us > dma_us ? mfma_us : dma_us;
+        if (cost[k] < 1.0) cost[k] = 1.0;
         cost_sum += cost[k];
     }
     int block = 0;
     int64_t off = 0;
     for (int k = 0; k < n; ++k) {
-        int64_t s = (int64_t)cus * cost[k] / cost_sum;
+        int64_t s = (int64_t)(cus * cost[k] / cost_sum);
         if (s < 1) s = 1;
         if (s > tiles) s = tiles;
         T.g[k].first_block = block;
@@ -496,7 +546,7 @@ NERF_API int nerf_mlp_backward(const void *packed, const float *params, const fl
                        plan.table, sv, static_cast<const float *>(dy), partial, M);
     rc = nerf::check_launch("nerf_mlp_backward: dW");
     if (rc != NERF_OK) return rc;
-    hipLaunchKernelGGL(mlp_bwd_out_kernel, dim3(OUT_BLOCKS), dim3(128), 0, s, sv, rgb, g_rgb, M, partial_out);
+    hipLaunchKernelGGL(mlp_bwd_out_kernel, dim3(OUT_BLOCKS), dim3(512), 0, s, sv, rgb, g_rgb, M, partial_out);
     rc = nerf::check_launch("nerf_mlp_backward: fc_out");
     if (rc != NERF_OK) return rc;
     hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(64, plan.table.n + 1), dim3(256), 0, s, plan.table,

@@ -123,17 +123,18 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[8], const float *bias, i
         }
 }
 
-// row m of a row-major plane <- this lane's 4-feature groups; rows beyond M are written as zeros
+// row m of a row-major plane <- this lane's 4-feature groups.  Stores are unconditional: rows in
+// [M, MP) receive the (finite) values of the clamped lane.  The backward GEMMs stay exact because
+// the GRADIENT planes hold exact zeros there (upstream gradients of padded lanes are zero), so a
+// padded row contributes 0 * finite = 0 to every sum.
 template <int NFB>
-__device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, bool valid, int h,
-                                           const f32x16 *blk) {
+__device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, int h, const f32x16 *blk) {
     float *row = plane + m * width + 4 * h;
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
-            if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4 *>(row + 32 * fb + 8 * q) = v;
         }
 }
@@ -142,7 +143,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ReLU sign bits of a layer: dword fb>>1, bit 16*(fb&1)+r  <-  blk[fb][r] > 0
 template <int NFB>
-__device__ __forceinline__ void save_mask(float *mask_plane, int64_t m, bool valid, int h, const f32x16 *blk) {
+__device__ __forceinline__ void save_mask(float *mask_plane, int64_t m, int h, const f32x16 *blk) {
     u32x4 bits = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
@@ -151,7 +152,6 @@ __device__ __forceinline__ void save_mask(float *mask_plane, int64_t m, bool val
         for (int r = 0; r < 16; ++r) w |= (blk[fb][r] > 0.0f ? 1u : 0u) << r;
         bits[fb >> 1] |= w << (16 * (fb & 1));
     }
-    if (!valid) bits = u32x4{0u, 0u, 0u, 0u};
     reinterpret_cast<u32x4 *>(mask_plane)[2 * m + h] = bits;
 }
 

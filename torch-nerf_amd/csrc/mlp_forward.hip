@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
         }
         const int64_t MP = padded_rows(M);
         if (SAVE) {
-            save_plane<2>(saved + pl_pe(MP), 64, m, valid, h, pe);
-            save_plane<1>(saved + pl_de(MP), 32, m, valid, h, &de);
+            save_plane<2>(saved + pl_pe(MP), 64, m, h, pe);
+            save_plane<1>(saved + pl_de(MP), 32, m, h, &de);
         }
 
         f32x16 acc[8], act[8];
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) act[fb][r] = fmaxf(acc[fb][r], 0.0f);
         if (SAVE) {
-            save_plane<8>(saved + pl_h(MP, 0), 256, m, valid, h, act);
-            save_mask<8>(saved + pl_masks(MP), m, valid, h, act);
+            save_plane<8>(saved + pl_h(MP, 0), 256, m, h, act);
+            save_mask<8>(saved + pl_masks(MP), m, h, act);
         }
 
         // ---- fc_1 .. fc_8 (nerf.py:103-113); skip connection at fc_5 (pos FIRST, :108)
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) act[fb][r] = fmaxf(acc[fb][r], floor_);
             if (SAVE) {
-                save_plane<8>(saved + pl_h(MP, l), 256, m, valid, h, act);  // l = 8 lands on PL_Y8
-                if (l < 8) save_mask<8>(saved + pl_masks(MP) + (int64_t)l * MP * 8, m, valid, h, act);
+                save_plane<8>(saved + pl_h(MP, l), 256, m, h, act);  // l = 8 lands on PL_Y8
+                if (l < 8) save_mask<8>(saved + pl_masks(MP) + (int64_t)l * MP * 8, m, h, act);
             }
         }
         sigma_pre += __shfl_xor(sigma_pre, 32, WAVE);
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[fb][r] = fmaxf(acc[fb][r], 0.0f);
         if (SAVE) {
-            save_plane<4>(saved + pl_h9(MP), 128, m, valid, h, acc);
-            save_mask<4>(saved + pl_masks(MP) + (int64_t)8 * MP * 8, m, valid, h, acc);
+            save_plane<4>(saved + pl_h9(MP), 128, m, h, acc);
+            save_mask<4>(saved + pl_masks(MP) + (int64_t)8 * MP * 8, m, h, acc);
         }
 
         // ---- fc_out + sigmoid (:119) on the vector ALU: 3 x 128 MACs per sample

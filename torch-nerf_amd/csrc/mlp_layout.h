@@ -80,8 +80,8 @@ constexpr int RING_SLOTS = 4;
 constexpr int LDS_BYTES = RING_SLOTS * CHUNK_BYTES + CONST_BYTES;  // 144384 <= 160 KiB
 
 // ---- activation record written by the training-mode forward.  All planes are row-major
-// with MP = M rounded up to a multiple of 128 rows; rows >= M are written as zeros so that the
-// backward GEMMs may consume whole 32-row tiles.
+// with MP = M rounded up to a multiple of 128 rows so that the backward GEMMs may consume whole
+// 32-row tiles; rows >= M hold finite filler here and exact zeros in the gradient planes.
 //   float planes (offsets in floats, x MP):
 //     PL_PE   : encoded position, 64 floats/sample (63 + one zero)
 //     PL_H(l) : post-ReLU outputs of fc_in (l=0), fc_1 .. fc_7 (l=7), 256 floats/sample

@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))            # .../torch-nerf_amd
 CSRC = os.path.join(PKG_ROOT, "csrc")
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libnerf_amd.so")
+LIB_PATH = os.environ.get("NERF_AMD_LIB", os.path.join(PKG_ROOT, "lib", "libnerf_amd.so"))
 
 _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int

@@ -220,7 +220,7 @@ class NerfMLPFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, view_dir, encoded, packed, flat_params, *params):
-        need_grad = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        need_grad = any(ctx.needs_input_grad[5:])  # grad mode is off inside forward(); ask the graph
         ctx.encoded = bool(encoded)
         ctx.shapes = [p.shape for p in params]
         if pos.requires_grad or view_dir.requires_grad:
