@@ -88,6 +88,38 @@ def host_cores():
     return cores
 
 
+def train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank, steps, warmup):
+    """Secondary figure: full training step (runners/train.py:120-218 without the .item() syncs):
+    coarse + fine forward with activation record, MSE coarse + MSE fine, backward through the
+    integrator and both MLPs (hand-written kernels), Adam step."""
+    params = [p for net in nets for p in net.parameters()]
+    opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8)
+    mse = torch.nn.MSELoss()
+    gt = torch.rand((RAYS, 3), device=device)
+
+    def step(s):
+        opt.zero_grad(set_to_none=True)
+        c_rgb, c_idx, c_w = renderer.render_scene(scene_c, RAYS, N_COARSE, False, local_rank, pixel_indices=pix[s])
+        f_rgb, _, _ = renderer.render_scene(scene_f, RAYS, (N_COARSE, N_FINE), False, local_rank,
+                                            pixel_indices=c_idx, weights=c_w)
+        loss = mse(gt, c_rgb) + mse(gt, f_rgb)
+        loss.backward()
+        opt.step()
+
+    for s in range(warmup):
+        step(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(warmup, warmup + steps):
+        step(s % len(pix))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flop = RAYS * (N_COARSE + N_COARSE + N_FINE) * 2 * (593408 + 1151104)   # BASELINE.md: fwd + bwd
+    return {"rays_per_s": RAYS * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "what": "fwd+bwd+Adam, both networks, 4096 rays x (64 + 192) samples",
+            "mfma_frac_of_peak": flop / (dt / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+
+
 def cpu_baseline(flats, focal, pose, device):
     """Eager-torch CPU port on the host cores; returns the JSON object + PSNR of HIP vs port."""
     from oracle import torch_port as TP
@@ -140,6 +172,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary fwd+bwd+Adam measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -229,6 +262,9 @@ def main():
                    "parallelism": f"ray-shard x{world}" + (" + all-gather" if world > 1 else "")},
         "roofline": roofline,
     }
+    if world == 1 and not args.no_train:
+        result["train"] = train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank,
+                                    max(3, args.steps // 4), 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, quality = cpu_baseline(flats, focal, pose, device)
         result["cpu_baseline"] = base

@@ -213,14 +213,16 @@ def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved,
 class NerfMLPFunction(torch.autograd.Function):
     """sigma, rgb = NeRF(encode(pos), encode(dir)) with hand-written forward and backward.
 
-    apply(pos, view_dir, encoded, packed, flat_params, *params): `params` are the 22
+    apply(pos, view_dir, encoded, record, packed, flat_params, *params): `params` are the 22
     nn.Parameters in state_dict order (present so autograd routes their gradients);
-    `flat_params` is their concatenation and `packed` its LDS-image stream.
+    `flat_params` is their concatenation and `packed` its LDS-image stream.  `record` selects the
+    training-mode kernel that also writes the activation record for backward; the caller decides
+    it from torch.is_grad_enabled() (grad mode is always off inside forward()).
     """
 
     @staticmethod
-    def forward(ctx, pos, view_dir, encoded, packed, flat_params, *params):
-        need_grad = any(ctx.needs_input_grad[5:])  # grad mode is off inside forward(); ask the graph
+    def forward(ctx, pos, view_dir, encoded, record, packed, flat_params, *params):
+        need_grad = bool(record)
         ctx.encoded = bool(encoded)
         ctx.shapes = [p.shape for p in params]
         if pos.requires_grad or view_dir.requires_grad:
@@ -249,7 +251,7 @@ class NerfMLPFunction(torch.autograd.Function):
                 n *= s
             grads.append(g_flat[off:off + n].view(shp))
             off += n
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------- integrator

@@ -63,6 +63,10 @@ class NeRF(nn.Module):
             self._pack_key = key
         return params, self._flat, self._packed
 
+    @staticmethod
+    def _wants_grad(params) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
     # ------------------------------------------------------------------ forward paths
     def forward(self, pos: torch.Tensor, view_dir: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """pos (M,63), view_dir (M,27): already encoded.  sigma = relu(.), rgb = sigmoid(.)."""
@@ -75,7 +79,7 @@ class NeRF(nn.Module):
         if view_dir.shape[-1] != self._view_dir_dim:
             raise ValueError(f"Expected {self._view_dir_dim}-D view direction vector. Got {view_dir.shape[-1]}.")
         params, flat, packed = self._stream()
-        return ops.NerfMLPFunction.apply(pos, view_dir, True, packed, flat, *params)
+        return ops.NerfMLPFunction.apply(pos, view_dir, True, self._wants_grad(params), packed, flat, *params)
 
     def accepts_fused_encoders(self, coord_enc, dir_enc) -> bool:
         """True if the two encoders are exactly what the fused kernel computes in registers."""
@@ -88,7 +92,7 @@ class NeRF(nn.Module):
     def forward_fused(self, points: torch.Tensor, view_dirs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """points, view_dirs (M,3) RAW: positional encoding happens inside the kernel."""
         params, flat, packed = self._stream()
-        return ops.NerfMLPFunction.apply(points, view_dirs, False, packed, flat, *params)
+        return ops.NerfMLPFunction.apply(points, view_dirs, False, self._wants_grad(params), packed, flat, *params)
 
     pos_dim = property(lambda self: self._pos_dim)
     view_dir_dim = property(lambda self: self._view_dir_dim)
