@@ -1,2 +1,5 @@
-from torch_nerf.src.network.nerf import *  # noqa: F401,F403
-from torch_nerf.src.network.instant_ngp import *  # noqa: F401,F403
+"""Radiance-field networks: `NeRF` (HIP kernels) and the out-of-scope `InstantNeRF` name."""
+from torch_nerf.src.network.instant_ngp import InstantNeRF
+from torch_nerf.src.network.nerf import NeRF
+
+__all__ = ["NeRF", "InstantNeRF"]

@@ -1,0 +1,1 @@
+"""Cameras, ray samplers, integrators and the volume renderer (HIP-backed)."""

@@ -1,0 +1,1 @@
+"""Numerical integrators; `quadrature_integrator.QuadratureIntegrator` is the one the runners build."""

@@ -11,7 +11,7 @@ from typing import Tuple, Union
 import torch
 
 from torch_nerf.amd import ops
-from torch_nerf.src.renderer.ray_samplers.sampler_base import *  # noqa: F401,F403
+
 from torch_nerf.src.renderer.ray_samplers.sampler_base import RayBundle, RaySamplerBase
 from torch_nerf.src.renderer.ray_samplers.utils import sample_pdf  # noqa: F401  (re-export, as the reference)
 

@@ -1,2 +1,5 @@
-from torch_nerf.src.scene.primitives.primitive_base import PrimitiveBase  # noqa: F401
-from torch_nerf.src.scene.primitives.cube import PrimitiveCube  # noqa: F401
+"""Scene primitives (query structures wrapping a radiance field and its encoders)."""
+from torch_nerf.src.scene.primitives.cube import PrimitiveCube
+from torch_nerf.src.scene.primitives.primitive_base import PrimitiveBase
+
+__all__ = ["PrimitiveBase", "PrimitiveCube"]
