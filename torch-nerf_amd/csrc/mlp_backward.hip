@@ -12,10 +12,14 @@
 //     reduction dimension.  A workgroup owns one (layer, sample-slice) item, keeps the whole
 //     256 x K_l tile in accumulators (up to 256 VGPRs per lane), and streams 32-row tiles of
 //     dY and X -- contiguous in HBM -- into a double-buffered LDS stage by LDS-DMA.
-//     Bias gradients and the density row of fc_8 ride along as vector-ALU side jobs.
+//     Bias gradients ride along for free: the A fragments ARE the dY values to be summed.
 //     2 KB of HBM reads per sample-layer for 131 kFLOP: intensity 64 FLOP/B, MFMA-bound.
-//  3. a deterministic reduction of the per-slice partial tiles into the flat gradient blob
-//     (state_dict layout), plus a small vector kernel for fc_out (3 x 128).
+//  3. thin outer products on the vector ALU (mlp_bwd_vec_kernel: fc_out 3 x 128 and the density
+//     row of fc_8), then a deterministic reduction of all per-slice / per-block partials into the
+//     flat gradient blob (state_dict layout).  No atomics anywhere: gradients are reproducible.
+#include <stdlib.h>
+#include <vector>
+
 #include "mlp_device.h"
 
 namespace {
@@ -148,9 +152,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 // stage 2: dW GEMMs
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_GEMMS = 13;
-constexpr int SLICE_EXTRA = 1024;  // floats reserved after each partial tile: bias (<=256) + density row (<=257)
+constexpr int SLICE_EXTRA = 256;  // floats reserved after each partial tile: the bias partial
 constexpr int DW_LDS_BYTES = 131072;  // 2 stages of 64 KiB (wide X) or 3 stages of 40 KiB (thin X)
-enum { FLAG_BIAS = 1, FLAG_DENSITY = 2 };
+enum { FLAG_BIAS = 1 };
 
 struct GemmDesc {
     int64_t a_off;        // dY plane, float offset into the dy workspace
@@ -191,20 +195,22 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
     constexpr int AW = 128 * NA;  // a_width: each of the 4 waves owns 32*NA rows
     constexpr int XW = 32 * KB;
     constexpr int A_PIECES = 32 * AW * 4 / 1024 / 4;  // 1-KiB DMA pieces per wave
-    constexpr int X_PIECES = 32 * XW * 4 / 1024;      // pieces for the whole X tile (4 | 8 | 32)
+    constexpr int X_PIECES = 32 * XW * 4 / 1024 / 4;  // per wave (X tile = 4 | 8 | 32 pieces)
     constexpr int A_BYTES = 32 * AW * 4, X_BYTES = 32 * XW * 4;
     constexpr int STAGE_BYTES = A_BYTES + X_BYTES;
     // thin X tiles finish their MFMAs faster than one DMA round trip: keep two tiles in flight
     constexpr int NSTAGE = (KB <= 2) ? 3 : 2;
     static_assert(NSTAGE * STAGE_BYTES <= DW_LDS_BYTES, "stage ring exceeds the LDS allocation");
-    constexpr int PER_WAVE = A_PIECES + X_PIECES / 4;  // DMA instructions per wave per tile
+    constexpr int PER_WAVE = A_PIECES + X_PIECES;  // DMA instructions per wave per tile
     const int i = lane & 31, h = lane >> 5;
     const int64_t tiles_total = MP / 32;
-    const int64_t t0 = tiles_total * slice / g.num_slices;
-    const int64_t t1 = tiles_total * (slice + 1) / g.num_slices;
-    const char *a_src = reinterpret_cast<const char *>(dy + g.a_off);
-    const char *x_src = reinterpret_cast<const char *>(saved + g.x_off);
-    const float *dsig = dy + dsig_plane(MP);
+    const int num_slices = g.num_slices;
+    const bool want_bias = (g.flags & FLAG_BIAS) != 0;
+    const int64_t t0 = tiles_total * slice / num_slices;
+    const int64_t t1 = tiles_total * (slice + 1) / num_slices;
+    const char *a_src = reinterpret_cast<const char *>(dy + g.a_off) + lane * 16;
+    const char *x_src = reinterpret_cast<const char *>(saved + g.x_off) + lane * 16;
+    float *out = partial + g.partial_off + slice * slice_stride(g);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
 
     f32x16 acc[NA][KB];
@@ -214,23 +220,19 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
         for (int b = 0; b < KB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    float bias_acc = 0.0f, dens_acc = 0.0f, dens_b = 0.0f;
+    float bsum[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) bsum[a] = 0.0f;
 
     auto issue = [&](int64_t t, int buf) {
-        const char *as = a_src + t * (32 * AW * 4) + lane * 16;
+        const char *as = a_src + t * A_BYTES;
         const unsigned ad = lds_base + buf * STAGE_BYTES;
 #pragma unroll
-        for (int j = 0; j < A_PIECES; ++j) {
-            const int p = wave + 4 * j;
-            lds_dma_16(as + p * 1024, ad + p * 1024);
-        }
-        const char *xs = x_src + t * (32 * XW * 4) + lane * 16;
-        const unsigned xd = lds_base + buf * STAGE_BYTES + A_BYTES;
+        for (int j = 0; j < A_PIECES; ++j) lds_dma_16(as + (wave + 4 * j) * 1024, ad + (wave + 4 * j) * 1024);
+        const char *xs = x_src + t * X_BYTES;
+        const unsigned xd = ad + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < (X_PIECES + 3) / 4; ++j) {
-            const int p = wave + 4 * j;
-            if (p < X_PIECES) lds_dma_16(xs + p * 1024, xd + p * 1024);
-        }
+        for (int j = 0; j < X_PIECES; ++j) lds_dma_16(xs + (wave + 4 * j) * 1024, xd + (wave + 4 * j) * 1024);
     };
 
     // prologue: NSTAGE-1 tiles in flight (tiles past the end are re-reads of the last tile: the
@@ -247,44 +249,28 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
             if (nb >= NSTAGE) nb -= NSTAGE;
             issue(tn < t1 ? tn : t1 - 1, nb);
         }
-        const float *A = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES);
-        const float *X = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES + A_BYTES);
-        // side jobs on the vector ALU: column sums of dY (bias) and the density row of fc_8
-        if ((g.flags & FLAG_BIAS) && tid < AW) {
-            float s = 0.0f;
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) s += A[r * AW + tid];
-            bias_acc += s;
-        }
-        if (g.flags & FLAG_DENSITY) {
-            float s = 0.0f, sb = 0.0f;
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) {
-                const float ds = dsig[t * 32 + r];
-                sb += ds;
-                if (tid < XW) s = fmaf(ds, X[r * XW + tid], s);
-            }
-            dens_acc += s;
-            dens_b += sb;
-        }
-        // dW += dY^T X over the 32 samples of the tile: 16 k-steps of 2 samples
+        const float *A = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES) + wave * 32 * NA + i;
+        const float *X = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES + A_BYTES) + i;
+        // dW += dY^T X over the 32 samples of the tile: 16 k-steps of 2 samples.  The A fragments
+        // (dY values) double as the bias-gradient summands: db[n] = sum over samples of dY[m][n].
 #pragma unroll 4
         for (int s = 0; s < 16; ++s) {
             float a[NA], b[KB];
 #pragma unroll
-            for (int nb = 0; nb < NA; ++nb) a[nb] = A[(2 * s + h) * AW + wave * 32 * NA + 32 * nb + i];
+            for (int nb = 0; nb < NA; ++nb) a[nb] = A[(2 * s + h) * AW + 32 * nb];
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) b[kb] = X[(2 * s + h) * XW + 32 * kb + i];
+            for (int kb = 0; kb < KB; ++kb) b[kb] = X[(2 * s + h) * XW + 32 * kb];
 #pragma unroll
-            for (int nb = 0; nb < NA; ++nb)
+            for (int nb = 0; nb < NA; ++nb) {
+                bsum[nb] += a[nb];
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
                     acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], b[kb], acc[nb][kb], 0, 0, 0);
+            }
         }
         buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     }
-    // partial tile of this slice: row-major [AW][XW], then bias[AW], then density row [XW] + its bias
-    float *out = partial + g.partial_off + slice * slice_stride(g);
+    // partial tile of this slice: row-major [AW][XW], then bias[AW]
 #pragma unroll
     for (int nb = 0; nb < NA; ++nb)
 #pragma unroll
@@ -294,17 +280,18 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
                 const int n = wave * 32 * NA + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;
                 out[n * XW + 32 * kb + i] = acc[nb][kb][r];
             }
-    float *extra = out + AW * XW;
-    if ((g.flags & FLAG_BIAS) && tid < AW) extra[tid] = bias_acc;
-    if (g.flags & FLAG_DENSITY) {
-        if (tid < XW) extra[256 + tid] = dens_acc;
-        if (tid == 0) extra[256 + XW] = dens_b;
+#pragma unroll
+    for (int nb = 0; nb < NA; ++nb) {
+        const float both = bsum[nb] + __shfl_xor(bsum[nb], 32, WAVE);  // even + odd samples
+        if (want_bias && h == 0) out[AW * XW + wave * 32 * NA + 32 * nb + i] = both;
     }
 }
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, const float *__restrict__ saved,
                                                              const float *__restrict__ dy,
-                                                             float *__restrict__ partial, int64_t M) {
+                                                             float *__restrict__ partial, int64_t M,
+                                                             unsigned long long *__restrict__ block_clocks) {
+    const unsigned long long clk0 = block_clocks ? wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -321,76 +308,109 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, con
     else if (g.a_width == 128 && g.x_width == 256) dw_body<1, 8>(g, slice, saved, dy, partial, MP, lds, tid, lane, wave);
     else dw_body<1, 1>(g, slice, saved, dy, partial, MP, lds, tid, lane, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (block_clocks && tid == 0) block_clocks[blockIdx.x] = wall_clock64() - clk0;  // 100 MHz ticks
 }
 
-// fc_out (3 x 128) and its bias on the vector ALU: block b sums samples [b*chunk, (b+1)*chunk);
-// 4 groups of 128 threads take every 4th sample, 2 samples in flight each, combined through LDS.
-constexpr int OUT_BLOCKS = 512;
-constexpr int OUT_STRIDE = 512;  // 3*128 weights + 3 biases, padded
-__global__ __launch_bounds__(512) void mlp_bwd_out_kernel(const float *__restrict__ saved,
+// Thin outer-product sums on the vector ALU (an MFMA row block would be 3/32 resp. 1/32 used):
+//   job 0: fc_out   dW[c][k] = sum_m gy10[m][c] h9[m][k]  (3 x 128), db[c] = sum_m gy10[m][c]
+//   job 1: fc_8 row 0 (density)   dW[0][k] = sum_m dsig[m] h7[m][k]  (256), db[0] = sum_m dsig[m]
+// Block b of a job sums samples [b*chunk, (b+1)*chunk) with 8 rows in flight per thread group;
+// HBM-bound: reads the h9 (512 B/sample) resp. h7 (1 KB/sample) plane once.
+constexpr int VEC_BLOCKS = 1024;   // per job
+constexpr int VEC_STRIDE = 512;    // floats per block partial: job 0 uses 387, job 1 uses 257
+__global__ __launch_bounds__(256) void mlp_bwd_vec_kernel(const float *__restrict__ saved,
+                                                          const float *__restrict__ dy,
                                                           const float *__restrict__ rgb,
                                                           const float *__restrict__ g_rgb, int64_t M,
-                                                          float *__restrict__ partial_out) {
-    __shared__ float red[4][3 * HALF + 4];
+                                                          float *__restrict__ partial_vec) {
+    __shared__ float red[2][3 * HALF + 4];
     const int64_t MP = padded_rows(M);
+    const int job = blockIdx.y;
+    const int64_t chunk = (M + VEC_BLOCKS - 1) / VEC_BLOCKS;
+    const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
+    float *out = partial_vec + ((int64_t)job * VEC_BLOCKS + blockIdx.x) * VEC_STRIDE;
+    constexpr int U = 8;
+    if (job == 1) {
+        const float *h7 = saved + pl_h(MP, 7);
+        const float *dsig = dy + dsig_plane(MP);
+        const int k = threadIdx.x;
+        float w = 0.f, b = 0.f;
+        int64_t m = lo;
+        for (; m + U <= hi; m += U) {
+            float x[U], d[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { x[u] = h7[(m + u) * FEAT + k]; d[u] = dsig[m + u]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { w = fmaf(d[u], x[u], w); b += d[u]; }
+        }
+        for (; m < hi; ++m) { const float d = dsig[m]; w = fmaf(d, h7[m * FEAT + k], w); b += d; }
+        out[k] = w;
+        if (k == 0) out[FEAT] = b;
+        return;
+    }
     const float *h9 = saved + pl_h9(MP);
     const int k = threadIdx.x & (HALF - 1), grp = threadIdx.x >> 7;
-    const int64_t chunk = (M + OUT_BLOCKS - 1) / OUT_BLOCKS;
-    const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
     float w[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
-    float w2[3] = {0.f, 0.f, 0.f}, b2[3] = {0.f, 0.f, 0.f};
-    auto grad = [&](int64_t m, float (&gy)[3]) {
+    int64_t m = lo + grp;
+    for (; m + 2 * (U - 1) < hi; m += 2 * U) {
+        float x[U], gy[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t mm = m + 2 * u;
+            x[u] = h9[mm * HALF + k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float y = rgb[3 * mm + c];
+                gy[u][c] = g_rgb[3 * mm + c] * y * (1.0f - y);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { w[c] = fmaf(gy[u][c], x[u], w[c]); b[c] += gy[u][c]; }
+    }
+    for (; m < hi; m += 2) {
+        const float x = h9[m * HALF + k];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float y = rgb[3 * m + c];
-            gy[c] = g_rgb[3 * m + c] * y * (1.0f - y);
+            const float gy = g_rgb[3 * m + c] * y * (1.0f - y);
+            w[c] = fmaf(gy, x, w[c]);
+            b[c] += gy;
         }
-    };
-    int64_t m = lo + grp;
-    for (; m + 4 < hi; m += 8) {
-        float ga[3], gb[3];
-        grad(m, ga);
-        grad(m + 4, gb);
-        const float xa = h9[m * HALF + k], xb = h9[(m + 4) * HALF + k];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            w[c] = fmaf(ga[c], xa, w[c]);
-            w2[c] = fmaf(gb[c], xb, w2[c]);
-            b[c] += ga[c];
-            b2[c] += gb[c];
-        }
-    }
-    for (; m < hi; m += 4) {
-        float ga[3];
-        grad(m, ga);
-        const float xa = h9[m * HALF + k];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { w[c] = fmaf(ga[c], xa, w[c]); b[c] += ga[c]; }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        red[grp][c * HALF + k] = w[c] + w2[c];
-        if (k == 0) red[grp][3 * HALF + c] = b[c] + b2[c];
+        red[grp][c * HALF + k] = w[c];
+        if (k == 0) red[grp][3 * HALF + c] = b[c];
     }
     __syncthreads();
-    float *out = partial_out + (int64_t)blockIdx.x * OUT_STRIDE;
-    for (int e = threadIdx.x; e < 3 * HALF + 3; e += 512)
-        out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    for (int e = threadIdx.x; e < 3 * HALF + 3; e += 256) out[e] = red[0][e] + red[1][e];
 }
 
 // ------------------------------------------------------------------------------------------
 // stage 3: reduce partial tiles into the flat gradient (state_dict layout), fixed order
 // ------------------------------------------------------------------------------------------
 __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__ partial,
-                                      const float *__restrict__ partial_out, float *__restrict__ g_params) {
+                                      const float *__restrict__ partial_vec, float *__restrict__ g_params) {
     const int gi = blockIdx.y;
     const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    if (gi == table.n) {  // fc_out
-        for (int64_t e = e0; e < 3 * HALF + 3; e += step) {
-            float s = 0.0f;
-            for (int b = 0; b < OUT_BLOCKS; ++b) s += partial_out[(int64_t)b * OUT_STRIDE + e];
-            g_params[w_offset(10) + e] = s;  // weight (3,128) then bias (3): contiguous in the blob
+    if (gi >= table.n) {  // the two vector jobs
+        const int job = gi - table.n;
+        const int count = job == 0 ? 3 * HALF + 3 : FEAT + 1;
+        const float *src = partial_vec + (int64_t)job * VEC_BLOCKS * VEC_STRIDE;
+        for (int64_t e = e0; e < count; e += step) {
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            for (int b = 0; b < VEC_BLOCKS; b += 4) {
+                s0 += src[(int64_t)b * VEC_STRIDE + e];
+                s1 += src[(int64_t)(b + 1) * VEC_STRIDE + e];
+                s2 += src[(int64_t)(b + 2) * VEC_STRIDE + e];
+                s3 += src[(int64_t)(b + 3) * VEC_STRIDE + e];
+            }
+            const float s = (s0 + s1) + (s2 + s3);
+            if (job == 0) g_params[w_offset(10) + e] = s;  // fc_out weight (3,128) then bias (3): contiguous
+            else g_params[e < FEAT ? w_offset(8) + e : b_offset(8)] = s;  // fc_8.weight[0, :], fc_8.bias[0]
         }
         return;
     }
@@ -398,22 +418,17 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
     const float *base = partial + g.partial_off;
     const int64_t stride = slice_stride(g);
     const int64_t tile = (int64_t)g.a_width * g.valid_cols;
-    const int64_t total = tile + ((g.flags & FLAG_BIAS) ? g.a_width : 0) +
-                          ((g.flags & FLAG_DENSITY) ? g.x_width + 1 : 0);
+    const int64_t total = tile + ((g.flags & FLAG_BIAS) ? g.a_width : 0);
     for (int64_t e = e0; e < total; e += step) {
         int64_t src, dst;
         if (e < tile) {
             const int n = (int)(e / g.valid_cols), k = (int)(e % g.valid_cols);
             src = (int64_t)n * g.x_width + k;
             dst = g.w_off + (int64_t)(n + g.row0) * g.in_features + g.col0 + k;
-        } else if ((g.flags & FLAG_BIAS) && e < tile + g.a_width) {
+        } else {
             const int n = (int)(e - tile);
             src = (int64_t)g.a_width * g.x_width + n;
             dst = g.b_off + g.row0 + n;
-        } else {
-            const int k = (int)(e - tile - ((g.flags & FLAG_BIAS) ? g.a_width : 0));
-            src = (int64_t)g.a_width * g.x_width + 256 + k;
-            dst = k < g.x_width ? g.w_off + k : g.b_off;  // density row 0 of fc_8, then fc_8.bias[0]
         }
         float s = 0.0f;
         for (int sl = 0; sl < g.num_slices; ++sl) s += base[sl * stride + src];
@@ -449,18 +464,16 @@ Plan make_plan(int64_t M, int cus) {
     add(5, dy_plane(MP, 5), 256, pl_h(MP, 4), 256, E_POS, 256, 0, FLAG_BIAS);
     add(6, dy_plane(MP, 6), 256, pl_h(MP, 5), 256, 0, 256, 0, FLAG_BIAS);
     add(7, dy_plane(MP, 7), 256, pl_h(MP, 6), 256, 0, 256, 0, FLAG_BIAS);
-    add(8, dy_plane(MP, 8), 256, pl_h(MP, 7), 256, 0, 256, 1, FLAG_BIAS | FLAG_DENSITY);
+    add(8, dy_plane(MP, 8), 256, pl_h(MP, 7), 256, 0, 256, 1, FLAG_BIAS);
     add(9, dy9_plane(MP), 128, pl_y8(MP), 256, 0, 256, 0, FLAG_BIAS);
     add(9, dy9_plane(MP), 128, pl_de(MP), 32, FEAT, E_DIR, 0, 0);
     T.n = n;
-    // Slices proportional to the time one 32-row tile costs a workgroup, one workgroup per CU in
-    // total: max(MFMA time, tile bytes at ~20 GB/s of LDS-DMA per CU, ~1 us of round-trip floor).
+    // Slices proportional to the time one 32-row tile costs a workgroup (measured on MI355X, us):
+    // wide tiles are MFMA-bound (256 MFMAs/wave), thin ones are bound by the LDS-DMA round trip.
     double cost[MAX_GEMMS], cost_sum = 0;
     for (int k = 0; k < n; ++k) {
-        const double mfma_us = (T.g[k].a_width / 128) * (T.g[k].x_width / 32) * 16 * 64 / 2400.0;
-        const double dma_us = 32.0 * 4 * (T.g[k].a_width + T.g[k].x_width) / 20e3;
-        cost[k] = mfma_us > dma_us ? mfma_us : dma_us;
-        if (cost[k] < 1.0) cost[k] = 1.0;
+        const int aw = T.g[k].a_width, xw = T.g[k].x_width;
+        cost[k] = (aw == 256 && xw == 256) ? 7.6 : (aw == 256 && xw == 64) ? 2.5 : (aw == 128 && xw == 256) ? 4.4 : 1.3;
         cost_sum += cost[k];
     }
     int block = 0;
@@ -501,7 +514,7 @@ NERF_API int64_t nerf_mlp_backward_workspace_bytes(int64_t M) {
     const int64_t MP = mlp::padded_rows(M);
     // upper bound on the partial buffer that does not depend on the device: 2 x 256 slices of a full tile
     const int64_t partial = (int64_t)(2 * 256 + MAX_GEMMS) * (256 * 256 + SLICE_EXTRA);
-    return 4 * (align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE) + partial + (int64_t)OUT_BLOCKS * OUT_STRIDE);
+    return 4 * (align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE) + partial + (int64_t)2 * VEC_BLOCKS * VEC_STRIDE);
 }
 
 NERF_API int nerf_mlp_backward(const void *packed, const float *params, const float *pos,
@@ -533,7 +546,7 @@ NERF_API int nerf_mlp_backward(const void *packed, const float *params, const fl
     float *dy = static_cast<float *>(workspace);
     float *partial = dy + align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE);
     const Plan plan = make_plan(M, cus);
-    float *partial_out = partial + plan.partial_floats;
+    float *partial_vec = partial + plan.partial_floats;
     const float *sv = static_cast<const float *>(saved);
 
     const int64_t ntiles = MP / mlp::TILE_SAMPLES;
@@ -542,14 +555,32 @@ NERF_API int nerf_mlp_backward(const void *packed, const float *params, const fl
                        dy);
     int rc = nerf::check_launch("nerf_mlp_backward: dx chain");
     if (rc != NERF_OK) return rc;
+    // NERF_DW_TIMING=<file>: debugging aid, dumps per-workgroup durations of the dW kernel (syncs!)
+    const char *timing_path = getenv("NERF_DW_TIMING");
+    unsigned long long *clocks = nullptr;
+    if (timing_path && hipMalloc(&clocks, sizeof(unsigned long long) * plan.total_blocks) != hipSuccess) clocks = nullptr;
     hipLaunchKernelGGL(mlp_bwd_dw_kernel, dim3((unsigned)plan.total_blocks), dim3(256), DW_LDS_BYTES, s,
-                       plan.table, sv, static_cast<const float *>(dy), partial, M);
+                       plan.table, sv, static_cast<const float *>(dy), partial, M, clocks);
     rc = nerf::check_launch("nerf_mlp_backward: dW");
     if (rc != NERF_OK) return rc;
-    hipLaunchKernelGGL(mlp_bwd_out_kernel, dim3(OUT_BLOCKS), dim3(512), 0, s, sv, rgb, g_rgb, M, partial_out);
-    rc = nerf::check_launch("nerf_mlp_backward: fc_out");
+    if (clocks) {
+        std::vector<unsigned long long> host(plan.total_blocks);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(host.data(), clocks, sizeof(unsigned long long) * plan.total_blocks, hipMemcpyDeviceToHost);
+        (void)hipFree(clocks);
+        if (FILE *f = fopen(timing_path, "w")) {
+            for (int k = 0; k < plan.table.n; ++k)
+                for (int sl = 0; sl < plan.table.g[k].num_slices; ++sl)
+                    fprintf(f, "%d %d %d %d %llu\n", k, plan.table.g[k].a_width, plan.table.g[k].x_width, sl,
+                            host[plan.table.g[k].first_block + sl]);
+            fclose(f);
+        }
+    }
+    hipLaunchKernelGGL(mlp_bwd_vec_kernel, dim3(VEC_BLOCKS, 2), dim3(256), 0, s, sv, static_cast<const float *>(dy), rgb,
+                       g_rgb, M, partial_vec);
+    rc = nerf::check_launch("nerf_mlp_backward: vector sums");
     if (rc != NERF_OK) return rc;
-    hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(64, plan.table.n + 1), dim3(256), 0, s, plan.table,
-                       static_cast<const float *>(partial), static_cast<const float *>(partial_out), g_params);
+    hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(64, plan.table.n + 2), dim3(256), 0, s, plan.table,
+                       static_cast<const float *>(partial), static_cast<const float *>(partial_vec), g_params);
     return nerf::check_launch("nerf_mlp_backward: reduce");
 }
