@@ -24,6 +24,6 @@ def test_library_builds_loads_and_exports_header():
     assert lib.nerf_amd_abi_version() == 1
     assert lib.nerf_mlp_param_count() == 595844
     # sizes only -- no compute without a GPU
-    assert lib.nerf_mlp_packed_bytes() == 13312 + (77 + 68) * 32768
+    assert lib.nerf_mlp_packed_bytes() == 13312 + (78 + 68) * 32768
     assert lib.nerf_mlp_saved_bytes(128) == 128 * (2528 * 4 + 9 * 32)
     assert lib.nerf_mlp_saved_bytes(129) == 256 * (2528 * 4 + 9 * 32)  # rows padded to 128

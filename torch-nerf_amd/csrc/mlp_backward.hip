@@ -60,10 +60,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
     pipe.issued = 0;
     pipe.issue_pos = 0;
     pipe.consumed = 0;
-    pipe.n_chunks = BWD_CHUNKS;
+    pipe.n_pairs = BWD_CHUNKS / 2;
     __syncthreads();
-    pipe.issue();
-    pipe.issue();
     pipe.issue();
 
     const int64_t MP = padded_rows(M);
@@ -112,7 +110,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) mma_chunk<8>(acc, act[kb], lds + pipe.acquire(), offq);
+        for (int pr = 0; pr < 2; ++pr) {
+            const char *w = lds + pipe.acquire();
+            mma_chunk<8>(acc, act[2 * pr], w, offq);
+            mma_chunk<8>(acc, act[2 * pr + 1], w + CHUNK_BYTES, offq);
+        }
 #pragma unroll
         for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];  // fc_8 has no ReLU
         save_plane<8>(dy + dy_plane(MP, 8), 256, m, h, act);
@@ -136,7 +138,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
                     for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
             }
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) mma_chunk<8>(acc, act[kb], lds + pipe.acquire(), offq);
+            for (int pr = 0; pr < 4; ++pr) {
+                const char *w = lds + pipe.acquire();
+                mma_chunk<8>(acc, act[2 * pr], w, offq);
+                mma_chunk<8>(acc, act[2 * pr + 1], w + CHUNK_BYTES, offq);
+            }
             const u32x4 mk = masks[(int64_t)(l - 1) * MP * 2 + 2 * m + h];
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb)

@@ -63,32 +63,38 @@ __device__ __forceinline__ void lds_dma_16(const char *src, unsigned lds_dst) {
         : "memory");
 }
 
+// Weight stream -> LDS ring, one PAIR of 32-KiB chunks per step (= 256 MFMAs per wavefront).
+// The ring holds two pairs: while pair p is consumed, pair p+1 is in flight.  Each wave copies its
+// quarter of every chunk (8 one-KiB pieces); completion is per wave (vmcnt) + one workgroup barrier.
 struct Pipe {
     const char *src_lane;  // stream base + this lane's byte offset inside a chunk
     unsigned lds_wave;     // LDS byte address of ring slot 0 + this wave's offset
-    unsigned issued;       // chunks issued so far
-    int issue_pos;         // stream position (0..n_chunks-1) of the next chunk to issue
-    unsigned consumed;     // chunks consumed so far
-    int n_chunks;
+    unsigned issued;       // pairs issued so far
+    int issue_pos;         // stream position (in pairs) of the next pair to issue
+    unsigned consumed;     // pairs consumed so far
+    int n_pairs;
 
     __device__ __forceinline__ void issue() {
-        const char *s = src_lane + (size_t)issue_pos * CHUNK_BYTES;
-        const unsigned d = lds_wave + (issued & (RING_SLOTS - 1)) * CHUNK_BYTES;
+        const char *s = src_lane + (size_t)issue_pos * PAIR_BYTES;
+        const unsigned d = lds_wave + (issued & 1) * PAIR_BYTES;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) lds_dma_16(s + j * 1024, d + j * 1024);
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lds_dma_16(s + c * CHUNK_BYTES + j * 1024, d + c * CHUNK_BYTES + j * 1024);
         ++issued;
-        issue_pos = (issue_pos + 1 == n_chunks) ? 0 : issue_pos + 1;
+        issue_pos = (issue_pos + 1 == n_pairs) ? 0 : issue_pos + 1;
     }
-    // make the next chunk readable; returns the LDS byte offset (from slot 0) of its image
+    // make the next pair readable; returns the LDS byte offset (from slot 0) of its first chunk.
+    // Only the pair being acquired is outstanding at this point (the next one is issued below),
+    // so a plain vmcnt(0) is exact -- and stays exact whatever other loads/stores the wave has queued.
     __device__ __forceinline__ unsigned acquire() {
-        // three chunks (3 x 8 DMA instructions of this wave) are in flight: the oldest must land
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave's pieces landed; everyone left the slot refilled next
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's pieces landed; everyone left the pair refilled next
         asm volatile("" ::: "memory");
         issue();
-        const unsigned slot = consumed & (RING_SLOTS - 1);
+        const unsigned off = (consumed & 1) * PAIR_BYTES;
         ++consumed;
-        return slot * CHUNK_BYTES;
+        return off;
     }
 };
 

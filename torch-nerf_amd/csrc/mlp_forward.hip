@@ -10,8 +10,8 @@
 //    GEMM  Y^T = W X^T  on v_mfma_f32_32x32x2_f32: the D fragment of one layer IS the
 //    B fragment of the next -- activations never touch LDS or HBM
 //  * weights stream L2 -> LDS through a 4-slot ring of 32-KiB chunks filled by LDS-DMA
-//    (global_load_lds_dwordx4, issued 3 chunks ahead, counted vmcnt + one s_barrier per
-//    chunk), shared by the 4 wavefronts; A fragments come out of LDS with conflict-free
+//    (global_load_lds_dwordx4, one 64-KiB pair of chunks in flight while the previous pair is
+//    consumed: one vmcnt wait + one s_barrier per 256 MFMAs), shared by the 4 wavefronts; A fragments come out of LDS with conflict-free
 //    ds_read_b128 (XOR-swizzled rows)
 //  * positional encodings are computed in registers straight into B-fragment layout
 //  * bound: fp32 MFMA (9280 MFMAs = 38.0 MFLOP per 32 samples); HBM traffic 40 B/sample
@@ -51,13 +51,28 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
     pipe.issued = 0;
     pipe.issue_pos = 0;
     pipe.consumed = 0;
-    pipe.n_chunks = FWD_CHUNKS;
+    pipe.n_pairs = FWD_CHUNKS / 2;
     __syncthreads();
-    pipe.issue();
-    pipe.issue();
     pipe.issue();
 
     const int64_t ntiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES;
+    const int64_t MP = padded_rows(M);
+    const int in_w = ENCODED ? E_POS : 3, in_wd = ENCODED ? E_DIR : 3;
+
+    // raw inputs of the first tile; later tiles are prefetched one tile ahead
+    float raw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load_raw = [&](int64_t tile) {
+        if (ENCODED || tile >= ntiles) return;
+        int64_t mm = tile * TILE_SAMPLES + wave * 32 + i;
+        if (mm >= M) mm = M - 1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            raw[c] = pos[3 * mm + c];
+            raw[3 + c] = dir[3 * mm + c];
+        }
+    };
+    load_raw(blockIdx.x);
+
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t m = tile * TILE_SAMPLES + wave * 32 + i;
         const bool valid = m < M;
@@ -69,71 +84,86 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
-                pe[0][r] = pos[mc * E_POS + k];
-                pe[1][r] = (32 + k < E_POS) ? pos[mc * E_POS + 32 + k] : 0.0f;
-                de[r] = (k < E_DIR) ? dir[mc * E_DIR + k] : 0.0f;
+                pe[0][r] = pos[mc * in_w + k];
+                pe[1][r] = (32 + k < E_POS) ? pos[mc * in_w + 32 + k] : 0.0f;
+                de[r] = (k < E_DIR) ? dir[mc * in_wd + k] : 0.0f;
             }
         } else {
-            const float px = pos[3 * mc], py = pos[3 * mc + 1], pz = pos[3 * mc + 2];
-            const float dx = dir[3 * mc], dy = dir[3 * mc + 1], dz = dir[3 * mc + 2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
-                pe[0][r] = enc_feature(k, px, py, pz, E_POS);
-                pe[1][r] = enc_feature(32 + k, px, py, pz, E_POS);
-                de[r] = enc_feature(k, dx, dy, dz, E_DIR);
+                pe[0][r] = enc_feature(k, raw[0], raw[1], raw[2], E_POS);
+                pe[1][r] = enc_feature(32 + k, raw[0], raw[1], raw[2], E_POS);
+                de[r] = enc_feature(k, raw[3], raw[4], raw[5], E_DIR);
             }
-        }
-        const int64_t MP = padded_rows(M);
-        if (SAVE) {
-            save_plane<2>(saved + pl_pe(MP), 64, m, h, pe);
-            save_plane<1>(saved + pl_de(MP), 32, m, h, &de);
+            load_raw(tile + gridDim.x);  // next tile's points: a whole tile of MFMAs hides the latency
         }
 
         f32x16 acc[8], act[8];
 
-        // ---- fc_in + ReLU (nerf.py:102)
-        load_bias<8>(acc, cb + CB_BIAS, h);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) mma_chunk<8>(acc, pe[kb], lds + pipe.acquire(), offq);
-#pragma unroll
-        for (int fb = 0; fb < 8; ++fb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) act[fb][r] = fmaxf(acc[fb][r], 0.0f);
-        if (SAVE) {
-            save_plane<8>(saved + pl_h(MP, 0), 256, m, h, act);
-            save_mask<8>(saved + pl_masks(MP), m, h, act);
+        // ---- fc_in (nerf.py:102): one pair = the two 32-wide halves of the encoded position
+        {
+            const char *w = lds + pipe.acquire();
+            if (SAVE) {
+                save_plane<2>(saved + pl_pe(MP), 64, m, h, pe);
+                save_plane<1>(saved + pl_de(MP), 32, m, h, &de);
+            }
+            load_bias<8>(acc, cb + CB_BIAS, h);
+            mma_chunk<8>(acc, pe[0], w, offq);
+            mma_chunk<8>(acc, pe[1], w + CHUNK_BYTES, offq);
         }
 
-        // ---- fc_1 .. fc_8 (nerf.py:103-113); skip connection at fc_5 (pos FIRST, :108)
+        // ---- fc_1 .. fc_8 (nerf.py:103-113); skip connection at fc_5 (pos FIRST, :108).
+        // The ReLU / record / bias section of layer l-1 sits AFTER the acquire of layer l's first
+        // pair, so its vector-ALU work and stores overlap the DMA wait and the first MFMAs.
         float sigma_pre = 0.0f;
         for (int l = 1; l <= 8; ++l) {
-            if (l == 8) sigma_pre = half_dot<8>(cb + CB_W8ROW0, act, h);  // density row of fc_8
-            load_bias<8>(acc, l < 8 ? cb + CB_BIAS + l * 256 : cb + CB_BIAS8, h);
-            if (l == 5) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mma_chunk<8>(acc, pe[kb], lds + pipe.acquire(), offq);
-            }
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) mma_chunk<8>(acc, act[kb], lds + pipe.acquire(), offq);
-            const float floor_ = l < 8 ? 0.0f : -INFINITY;  // fc_8 has no ReLU (:113)
+            const char *w = lds + pipe.acquire();
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) act[fb][r] = fmaxf(acc[fb][r], floor_);
+                for (int r = 0; r < 16; ++r) act[fb][r] = fmaxf(acc[fb][r], 0.0f);  // ReLU of layer l-1
             if (SAVE) {
-                save_plane<8>(saved + pl_h(MP, l), 256, m, h, act);  // l = 8 lands on PL_Y8
-                if (l < 8) save_mask<8>(saved + pl_masks(MP) + (int64_t)l * MP * 8, m, h, act);
+                save_plane<8>(saved + pl_h(MP, l - 1), 256, m, h, act);
+                save_mask<8>(saved + pl_masks(MP) + (int64_t)(l - 1) * MP * 8, m, h, act);
             }
+            if (l == 8) sigma_pre = half_dot<8>(cb + CB_W8ROW0, act, h);  // density row of fc_8
+            load_bias<8>(acc, l < 8 ? cb + CB_BIAS + l * 256 : cb + CB_BIAS8, h);
+            if (l == 5) {
+                mma_chunk<8>(acc, pe[0], w, offq);
+                mma_chunk<8>(acc, pe[1], w + CHUNK_BYTES, offq);
+                w = lds + pipe.acquire();
+            }
+            mma_chunk<8>(acc, act[0], w, offq);
+            mma_chunk<8>(acc, act[1], w + CHUNK_BYTES, offq);
+#pragma unroll
+            for (int pr = 1; pr < 4; ++pr) {
+                w = lds + pipe.acquire();
+                mma_chunk<8>(acc, act[2 * pr], w, offq);
+                mma_chunk<8>(acc, act[2 * pr + 1], w + CHUNK_BYTES, offq);
+            }
+        }
+
+        // ---- fc_9 on cat([x[:,1:], view_dir]) -- features FIRST (:116-118); fc_8 has no ReLU (:113)
+        {
+            const char *w = lds + pipe.acquire();
+#pragma unroll
+            for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];
+            if (SAVE) save_plane<8>(saved + pl_y8(MP), 256, m, h, act);
+            load_bias<4>(acc, cb + CB_BIAS9, h);
+            mma_chunk<4>(acc, act[0], w, offq);
+            mma_chunk<4>(acc, act[1], w + CHUNK_BYTES, offq);
+#pragma unroll
+            for (int pr = 1; pr < 4; ++pr) {
+                w = lds + pipe.acquire();
+                mma_chunk<4>(acc, act[2 * pr], w, offq);
+                mma_chunk<4>(acc, act[2 * pr + 1], w + CHUNK_BYTES, offq);
+            }
+            w = lds + pipe.acquire();  // direction chunk + filler chunk
+            mma_chunk<4>(acc, de, w, offq);
         }
         sigma_pre += __shfl_xor(sigma_pre, 32, WAVE);
         const float sigma = fmaxf(sigma_pre + cb[CB_SCALARS], 0.0f);  // relu(x[:,0]) (:115)
-
-        // ---- fc_9 on cat([x[:,1:], view_dir]) -- features FIRST (:116-118)
-        load_bias<4>(acc, cb + CB_BIAS9, h);
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) mma_chunk<4>(acc, act[kb], lds + pipe.acquire(), offq);
-        mma_chunk<4>(acc, de, lds + pipe.acquire(), offq);
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll

@@ -11,7 +11,8 @@
 // 16 MFMA k-steps for that 32-feature block walk r = 0..15.  Activations therefore
 // never leave registers between layers; only weights move (L2 -> LDS -> A operand).
 //
-// Packed stream = [const block][chunk 0][chunk 1]...[chunk 76], consumed linearly.
+// Packed stream = [const block][chunk 0][chunk 1]...[chunk 77], consumed linearly, two chunks
+// (one "pair" = 64 KiB = 64 k-values) per pipeline step.
 // A chunk is the LDS image of W[:, 32 consecutive k] for one layer: 256 rows (output
 // features) x 128 B; row n holds eight 16-byte slots, logical slot c = (k%32)/4 is
 // stored at physical slot c ^ ((n>>1)&7) so that the ds_read_b128 of a 16-lane group
@@ -60,8 +61,9 @@ constexpr int CH_FC5_ENC = 34; // 2        : fc_5[:, 0:63]   (skip connection, p
 constexpr int CH_FC5 = 36;     // 8        : fc_5[:, 63:319]
 constexpr int CH_TRUNK6 = 44;  // 2 x 8    : fc_6, fc_7
 constexpr int CH_FC8 = 60;     // 8        : fc_8 rows 1..256
-constexpr int CH_FC9 = 68;     // 9        : fc_9[:, 0:256] then fc_9[:, 256:283] (dir, padded to 32); rows 0..127
-constexpr int FWD_CHUNKS = 77;
+constexpr int CH_FC9 = 68;     // 9 (+1)   : fc_9[:, 0:256] then fc_9[:, 256:283] (dir, padded to 32); rows 0..127;
+                               //            chunk 77 is zero filler so that the stream is a whole number of PAIRS
+constexpr int FWD_CHUNKS = 78;
 constexpr int64_t FWD_BYTES = (int64_t)CONST_BYTES + (int64_t)FWD_CHUNKS * CHUNK_BYTES;
 
 // ---- transposed stream for the backward dX chain (chunks of W^T: rows = INPUT feature,
@@ -75,8 +77,9 @@ constexpr int BWD_CHUNKS = 68;
 constexpr int64_t BWD_OFFSET = FWD_BYTES;
 constexpr int64_t PACKED_BYTES = FWD_BYTES + (int64_t)BWD_CHUNKS * CHUNK_BYTES;
 
-// ring of chunk slots in LDS
+// ring of chunk slots in LDS: 2 pair-slots of 2 chunks
 constexpr int RING_SLOTS = 4;
+constexpr int PAIR_BYTES = 2 * CHUNK_BYTES;
 constexpr int LDS_BYTES = RING_SLOTS * CHUNK_BYTES + CONST_BYTES;  // 144384 <= 160 KiB
 
 // ---- activation record written by the training-mode forward.  All planes are row-major

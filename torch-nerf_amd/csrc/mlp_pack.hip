@@ -1,5 +1,5 @@
 // Re-tiles the flat NeRF parameter blob (state_dict order) into the stream the fused
-// MLP kernels DMA into LDS: const block + 77 forward chunks + 68 transposed chunks
+// MLP kernels DMA into LDS: const block + 78 forward chunks + 68 transposed chunks
 // (layout: mlp_layout.h).  2.4 MB in, 4.8 MB out; runs once per parameter update.
 #include "common.h"
 #include "mlp_layout.h"
@@ -33,7 +33,8 @@ __device__ float forward_chunk_value(const float *P, int ci, int n, int kk) {
     if (ci < CH_FC9) return weight(P, 8, n + 1, 32 * (ci - CH_FC8) + kk);
     if (n >= HALF) return 0.0f;
     if (ci < CH_FC9 + 8) return weight(P, 9, n, 32 * (ci - CH_FC9) + kk);
-    return kk < E_DIR ? weight(P, 9, n, FEAT + kk) : 0.0f;
+    if (ci == CH_FC9 + 8) return kk < E_DIR ? weight(P, 9, n, FEAT + kk) : 0.0f;
+    return 0.0f;  // filler chunk (pairs)
 }
 
 // chunk of W^T: image row m = INPUT feature, k-group = 32 consecutive OUTPUT features
