@@ -112,8 +112,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
             const char *w = lds + pipe.acquire();
-            mma_chunk<8>(acc, act[2 * pr], w, offq);
-            mma_chunk<8>(acc, act[2 * pr + 1], w + CHUNK_BYTES, offq);
+            mma_pair<8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
         }
 #pragma unroll
         for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];  // fc_8 has no ReLU
@@ -140,8 +139,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
                 const char *w = lds + pipe.acquire();
-                mma_chunk<8>(acc, act[2 * pr], w, offq);
-                mma_chunk<8>(acc, act[2 * pr + 1], w + CHUNK_BYTES, offq);
+                mma_pair<8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
             }
             const u32x4 mk = masks[(int64_t)(l - 1) * MP * 2 + 2 * m + h];
 #pragma unroll

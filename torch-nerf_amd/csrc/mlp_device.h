@@ -74,33 +74,43 @@ struct Pipe {
     unsigned consumed;     // pairs consumed so far
     int n_pairs;
 
-    __device__ __forceinline__ void issue() {
-        const char *s = src_lane + (size_t)issue_pos * PAIR_BYTES;
-        const unsigned d = lds_wave + (issued & 1) * PAIR_BYTES;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) lds_dma_16(s + c * CHUNK_BYTES + j * 1024, d + c * CHUNK_BYTES + j * 1024);
+    // one of the 16 one-KiB pieces this wave copies per pair (piece 0..7 -> chunk 0, 8..15 -> chunk 1)
+    __device__ __forceinline__ void issue_piece(int piece) const {
+        const int c = piece >> 3, j = piece & 7;
+        lds_dma_16(src_lane + (size_t)issue_pos * PAIR_BYTES + c * CHUNK_BYTES + j * 1024,
+                   lds_wave + (issued & 1) * PAIR_BYTES + c * CHUNK_BYTES + j * 1024);
+    }
+    __device__ __forceinline__ void issue_done() {
         ++issued;
         issue_pos = (issue_pos + 1 == n_pairs) ? 0 : issue_pos + 1;
     }
-    // make the next pair readable; returns the LDS byte offset (from slot 0) of its first chunk.
-    // Only the pair being acquired is outstanding at this point (the next one is issued below),
-    // so a plain vmcnt(0) is exact -- and stays exact whatever other loads/stores the wave has queued.
+    __device__ __forceinline__ void issue() {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) issue_piece(p);
+        issue_done();
+    }
+    // Make the next pair readable; returns the LDS byte offset (from slot 0) of its first chunk.
+    // Only the pair being acquired is outstanding at this point, so a plain vmcnt(0) is exact --
+    // and stays exact whatever other loads/stores the wave has queued.  The copy of the FOLLOWING
+    // pair is not issued here: mma_pair() spreads its 16 DMA instructions between the MFMAs of
+    // this pair, where they issue for free behind the matrix pipe.
     __device__ __forceinline__ unsigned acquire() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's pieces landed; everyone left the pair refilled next
         asm volatile("" ::: "memory");
-        issue();
         const unsigned off = (consumed & 1) * PAIR_BYTES;
         ++consumed;
         return off;
     }
 };
 
-template <int NFB>
+// acc[fb] += W[32 fb .. 32 fb + 31][32 k-values of this chunk] . b   for NFB feature blocks.
+// If FIRST_PIECE >= 0, the wave also issues 8 LDS-DMA pieces of the next pair, one per q/fb group
+// position, interleaved with the MFMAs.
+template <int NFB, int FIRST_PIECE = -1>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, const char *chunk,
-                                          const int (&offq)[4]) {
+                                          const int (&offq)[4], const Pipe *pipe = nullptr) {
+    constexpr int GROUPS = 4 * NFB, EVERY = GROUPS / 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -108,10 +118,20 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, con
             const f32x4 a = *reinterpret_cast<const f32x4 *>(chunk + fb * 4096 + offq[q]);
             acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * q + 0], acc[fb], 0, 0, 0);
             acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * q + 1], acc[fb], 0, 0, 0);
+            if (FIRST_PIECE >= 0 && (q * NFB + fb) % EVERY == 0) pipe->issue_piece(FIRST_PIECE + (q * NFB + fb) / EVERY);
             acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * q + 2], acc[fb], 0, 0, 0);
             acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * q + 3], acc[fb], 0, 0, 0);
         }
     }
+}
+
+// one pipeline step: both chunks of the acquired pair, with the next pair's copy folded in
+template <int NFB>
+__device__ __forceinline__ void mma_pair(f32x16 (&acc)[8], const f32x16 &b0, const f32x16 &b1, const char *w,
+                                         const int (&offq)[4], Pipe &pipe) {
+    mma_chunk<NFB, 0>(acc, b0, w, offq, &pipe);
+    mma_chunk<NFB, 8>(acc, b1, w + CHUNK_BYTES, offq, &pipe);
+    pipe.issue_done();
 }
 
 // acc[fb][4q..4q+3] <- bias[32 fb + 8 q + 4 h ..]: the C fragment starts as the bias

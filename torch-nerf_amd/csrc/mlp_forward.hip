@@ -109,8 +109,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
                 save_plane<1>(saved + pl_de(MP), 32, m, h, &de);
             }
             load_bias<8>(acc, cb + CB_BIAS, h);
-            mma_chunk<8>(acc, pe[0], w, offq);
-            mma_chunk<8>(acc, pe[1], w + CHUNK_BYTES, offq);
+            mma_pair<8>(acc, pe[0], pe[1], w, offq, pipe);
         }
 
         // ---- fc_1 .. fc_8 (nerf.py:103-113); skip connection at fc_5 (pos FIRST, :108).
@@ -130,17 +129,14 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
             if (l == 8) sigma_pre = half_dot<8>(cb + CB_W8ROW0, act, h);  // density row of fc_8
             load_bias<8>(acc, l < 8 ? cb + CB_BIAS + l * 256 : cb + CB_BIAS8, h);
             if (l == 5) {
-                mma_chunk<8>(acc, pe[0], w, offq);
-                mma_chunk<8>(acc, pe[1], w + CHUNK_BYTES, offq);
+                mma_pair<8>(acc, pe[0], pe[1], w, offq, pipe);
                 w = lds + pipe.acquire();
             }
-            mma_chunk<8>(acc, act[0], w, offq);
-            mma_chunk<8>(acc, act[1], w + CHUNK_BYTES, offq);
+            mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
 #pragma unroll
             for (int pr = 1; pr < 4; ++pr) {
                 w = lds + pipe.acquire();
-                mma_chunk<8>(acc, act[2 * pr], w, offq);
-                mma_chunk<8>(acc, act[2 * pr + 1], w + CHUNK_BYTES, offq);
+                mma_pair<8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
             }
         }
 
@@ -151,16 +147,17 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
             for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];
             if (SAVE) save_plane<8>(saved + pl_y8(MP), 256, m, h, act);
             load_bias<4>(acc, cb + CB_BIAS9, h);
-            mma_chunk<4>(acc, act[0], w, offq);
-            mma_chunk<4>(acc, act[1], w + CHUNK_BYTES, offq);
+            mma_pair<4>(acc, act[0], act[1], w, offq, pipe);
 #pragma unroll
             for (int pr = 1; pr < 4; ++pr) {
                 w = lds + pipe.acquire();
-                mma_chunk<4>(acc, act[2 * pr], w, offq);
-                mma_chunk<4>(acc, act[2 * pr + 1], w + CHUNK_BYTES, offq);
+                mma_pair<4>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
             }
-            w = lds + pipe.acquire();  // direction chunk + filler chunk
-            mma_chunk<4>(acc, de, w, offq);
+            w = lds + pipe.acquire();  // direction chunk + filler chunk (not multiplied)
+            mma_chunk<4, 0>(acc, de, w, offq, &pipe);
+#pragma unroll
+            for (int p = 8; p < 16; ++p) pipe.issue_piece(p);
+            pipe.issue_done();
         }
         sigma_pre += __shfl_xor(sigma_pre, 32, WAVE);
         const float sigma = fmaxf(sigma_pre + cb[CB_SCALARS], 0.0f);  // relu(x[:,0]) (:115)
