@@ -68,6 +68,41 @@ def test_gather_image_world2_gloo():
         assert results == {0: True, 1: True}
 
 
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+        x = torch.arange(20, dtype=torch.float32).view(4, 5) * (rank + 1)
+        net(x).sum().backward()
+        local = [p.grad.clone() for p in net.parameters()]
+        shard.allreduce_gradients(list(net.parameters()))
+        q.put((rank, [g.numpy() for g in local], [p.grad.numpy() for p in net.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_gradients_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict()
+    for _ in range(2):
+        rank, local, reduced = q.get(timeout=120)
+        out[rank] = (local, reduced)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for k in range(4):
+        mean = (out[0][0][k] + out[1][0][k]) / 2
+        np.testing.assert_allclose(out[0][1][k], mean, rtol=1e-6)
+        np.testing.assert_allclose(out[1][1][k], mean, rtol=1e-6)
+
+
 def test_gather_image_single_process_passthrough():
     x = torch.rand(12, 3)
     assert shard.gather_image(x, 12) is x
