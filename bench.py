@@ -120,6 +120,35 @@ def train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank, steps, 
             "mfma_frac_of_peak": flop / (dt / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
 
 
+def bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank, steps, warmup):
+    """Secondary figure (BASELINE configs[2]): the same render step with bf16 weights / layer inputs on the
+    bf16 MFMA path, and its PSNR against the fp32 step on identical pixels and draws."""
+    def run(s, seed):
+        torch.manual_seed(seed)
+        return render_step(renderer, scene_c, scene_f, pix[s], local_rank)[1]
+
+    with torch.no_grad():
+        ref = run(0, 99)
+        for net in nets:
+            net.bf16_inference = True
+        got = run(0, 99)
+        mse = torch.mean((got.double() - ref.double()) ** 2).item()
+        for s in range(warmup):
+            run(s, s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(warmup, warmup + steps):
+            render_step(renderer, scene_c, scene_f, pix[s % len(pix)], local_rank)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        for net in nets:
+            net.bf16_inference = False
+    return {"rays_per_s": RAYS * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "psnr_vs_fp32_db": round(10.0 * np.log10(1.0 / mse), 2) if mse > 0 else None,
+            "max_abs_err_vs_fp32": (got - ref).abs().max().item(),
+            "what": "render step with bf16 weights + bf16 layer inputs (v_mfma_f32_32x32x16_bf16, fp32 accumulate)"}
+
+
 def cpu_baseline(flats, focal, pose, device):
     """Eager-torch CPU port on the host cores; returns the JSON object + PSNR of HIP vs port."""
     from oracle import torch_port as TP
@@ -173,6 +202,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary fwd+bwd+Adam measurement")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-MFMA render measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -268,6 +298,8 @@ def main():
                    "parallelism": f"ray-shard x{world}" + (" + all-gather" if world > 1 else "")},
         "roofline": roofline,
     }
+    if world == 1 and not args.no_bf16:
+        result["bf16"] = bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank, args.steps, 3)
     if world == 1 and not args.no_train:
         result["train"] = train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank,
                                     max(3, args.steps // 4), 2)

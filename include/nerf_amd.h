@@ -104,6 +104,15 @@ int64_t nerf_mlp_saved_bytes(int64_t M);
 int nerf_mlp_forward(const void *packed, const float *pos, const float *view_dir, int64_t M,
                      int encoded, float *sigma, float *rgb, void *saved, nerf_stream_t stream);
 
+/* ---- a10, bf16 variant (BASELINE configs[2]: "bf16 MLP weights on MFMA"), inference only.
+ * Weights and layer inputs are rounded to bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate); bias, ReLU,
+ * the density row, fc_out and the sigmoid stay fp32.  pos, view_dir are RAW (M,3).  Parity is a PSNR
+ * bound against nerf_mlp_forward, not the 1e-5 bound.  Same `params` blob as nerf_mlp_pack. */
+int64_t nerf_mlp_packed_bf16_bytes(void);
+int nerf_mlp_pack_bf16(const float *params, void *packed_bf16, nerf_stream_t stream);
+int nerf_mlp_forward_bf16(const void *packed_bf16, const float *pos, const float *view_dir, int64_t M,
+                          float *sigma, float *rgb, nerf_stream_t stream);
+
 /* ---- a13 (MLP part): gradients of all 22 parameter tensors (autograd in the
  * reference, entered at runners/train.py:215).  g_params (param_count floats, same
  * layout as `params`) is OVERWRITTEN.  workspace: nerf_mlp_backward_workspace_bytes(M). */

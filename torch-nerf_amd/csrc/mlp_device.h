@@ -134,6 +134,36 @@ __device__ __forceinline__ void mma_pair(f32x16 (&acc)[8], const f32x16 &b0, con
     pipe.issue_done();
 }
 
+// x = act(raw accumulator block + bias); `bias_blk` points at the 32 biases of the block
+template <bool RELU>
+__device__ __forceinline__ f32x16 finish_block(const f32x16 &raw, const float *bias_blk, int h) {
+    f32x16 x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_blk + 8 * q + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = raw[4 * q + j] + bv[j];
+            x[4 * q + j] = RELU ? fmaxf(v, 0.0f) : v;
+        }
+    }
+    return x;
+}
+
+// this lane's half of dot(w[32 features of a block], x); w in LDS
+__device__ __forceinline__ float block_dot(const float *w_blk, const f32x16 &x, int h) {
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(w_blk + 8 * q + 4 * h);
+        s = fmaf(v.x, x[4 * q + 0], s);
+        s = fmaf(v.y, x[4 * q + 1], s);
+        s = fmaf(v.z, x[4 * q + 2], s);
+        s = fmaf(v.w, x[4 * q + 3], s);
+    }
+    return s;
+}
+
 // acc[fb][4q..4q+3] <- bias[32 fb + 8 q + 4 h ..]: the C fragment starts as the bias
 template <int NFB>
 __device__ __forceinline__ void load_bias(f32x16 (&acc)[8], const float *bias, int h) {

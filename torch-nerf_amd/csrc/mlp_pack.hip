@@ -83,7 +83,59 @@ __global__ void pack_kernel(const float *__restrict__ P, float *__restrict__ out
     }
 }
 
+// ---- bf16 stream (mlp_layout.h "bf16 inference stream")
+__device__ float bf16_stream_value(const float *P, int step, int c, int n, int kk) {
+    if (step == 0) {
+        const int k = 32 * c + kk;
+        return (c < 2 && k < E_POS) ? weight(P, 0, n, k) : 0.0f;
+    }
+    if (step <= 8) return weight(P, 1 + (step - 1) / 2, n, 32 * (((step - 1) % 2) * 4 + c) + kk);
+    if (step == 9) {
+        const int k = 32 * c + kk;
+        return (c < 2 && k < E_POS) ? weight(P, 5, n, k) : 0.0f;
+    }
+    if (step <= 11) return weight(P, 5, n, E_POS + 32 * ((step - 10) * 4 + c) + kk);
+    if (step <= 15) return weight(P, 6 + (step - 12) / 2, n, 32 * (((step - 12) % 2) * 4 + c) + kk);
+    if (step <= 17) return weight(P, 8, n + 1, 32 * ((step - 16) * 4 + c) + kk);
+    if (n >= HALF) return 0.0f;
+    if (step <= 19) return weight(P, 9, n, 32 * ((step - 18) * 4 + c) + kk);
+    return (c == 0 && kk < E_DIR) ? weight(P, 9, n, FEAT + kk) : 0.0f;
+}
+
+__global__ void pack_bf16_kernel(const float *__restrict__ P, char *__restrict__ out) {
+    float *cblock = reinterpret_cast<float *>(out);
+    __bf16 *stream = reinterpret_cast<__bf16 *>(out + CONST_BYTES);
+    const int64_t n_bf16 = (int64_t)B16_STEPS * B16_STEP_BYTES / 2;
+    const int64_t total = CONST_FLOATS + n_bf16;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < CONST_FLOATS) {
+            cblock[e] = const_block_value(P, (int)e);
+            continue;
+        }
+        const int64_t r = e - CONST_FLOATS;            // bf16 element index in the stream
+        const int step = (int)(r / (B16_STEP_BYTES / 2));
+        const int in_step = (int)(r % (B16_STEP_BYTES / 2));
+        const int c = in_step / (B16_CHUNK_BYTES / 2);
+        const int b = (in_step % (B16_CHUNK_BYTES / 2)) * 2;  // byte offset inside the chunk image
+        const int n = b >> 6;                                 // row (64 B per row)
+        const int slot = ((b & 63) >> 4) ^ ((n >> 2) & 3);    // logical fragment 2s+h
+        const int el = (b & 15) >> 1;
+        const int kk = 16 * (slot >> 1) + 8 * (el >> 2) + 4 * (slot & 1) + (el & 3);
+        stream[r] = (__bf16)bf16_stream_value(P, step, c, n, kk);
+    }
+}
+
 }  // namespace
+
+NERF_API int64_t nerf_mlp_packed_bf16_bytes(void) { return mlp::B16_PACKED_BYTES; }
+
+NERF_API int nerf_mlp_pack_bf16(const float *params, void *packed, nerf_stream_t stream) {
+    NERF_REQUIRE(params && packed, "nerf_mlp_pack_bf16: null pointer");
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(1024), dim3(256), 0, nerf::as_stream(stream), params,
+                       reinterpret_cast<char *>(packed));
+    return nerf::check_launch("nerf_mlp_pack_bf16");
+}
 
 NERF_API int64_t nerf_mlp_param_count(void) { return mlp::PARAM_COUNT; }
 NERF_API int64_t nerf_mlp_packed_bytes(void) { return mlp::PACKED_BYTES; }

@@ -35,6 +35,9 @@ SIGNATURES = {
     "nerf_mlp_pack": (_c_int, [_p, _p, _p]),
     "nerf_mlp_saved_bytes": (_c_i64, [_c_i64]),
     "nerf_mlp_forward": (_c_int, [_p, _p, _p, _c_i64, _c_int, _p, _p, _p, _p]),
+    "nerf_mlp_packed_bf16_bytes": (_c_i64, []),
+    "nerf_mlp_pack_bf16": (_c_int, [_p, _p, _p]),
+    "nerf_mlp_forward_bf16": (_c_int, [_p, _p, _p, _c_i64, _p, _p, _p]),
     "nerf_mlp_backward_workspace_bytes": (_c_i64, [_c_i64]),
     "nerf_mlp_backward": (_c_int, [_p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_composite_forward": (_c_int, [_p, _p, _p, _c_i64, _c_int, _p, _p, _p]),

@@ -194,6 +194,34 @@ def mlp_forward(packed: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor,
     return (sigma, rgb, saved) if save else (sigma, rgb)
 
 
+def mlp_pack_bf16(flat_params: torch.Tensor) -> torch.Tensor:
+    """Flat fp32 state_dict blob -> bf16 fragment stream for mlp_forward_bf16 (uint8 GPU tensor)."""
+    lib = _lib.load()
+    flat_params = _gpu(flat_params, "flat_params")
+    if flat_params.numel() != lib.nerf_mlp_param_count():
+        raise ValueError(f"expected {lib.nerf_mlp_param_count()} parameters, got {flat_params.numel()}")
+    packed = torch.empty((lib.nerf_mlp_packed_bf16_bytes(),), dtype=torch.uint8, device=flat_params.device)
+    with torch.cuda.device(flat_params.device):
+        _lib.check(lib.nerf_mlp_pack_bf16(_ptr(flat_params), _ptr(packed), _stream()), "nerf_mlp_pack_bf16")
+    return packed
+
+
+def mlp_forward_bf16(packed_bf16: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor):
+    """Inference-only bf16-MFMA variant of the fused encode + NeRF forward; pos, view_dir raw (M,3)."""
+    lib = _lib.load()
+    pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
+    M = pos.shape[0]
+    sigma = torch.empty((M,), dtype=torch.float32, device=pos.device)
+    rgb = torch.empty((M, 3), dtype=torch.float32, device=pos.device)
+    with torch.cuda.device(pos.device):
+        end = _timed("mlp_forward_bf16", M)
+        _lib.check(lib.nerf_mlp_forward_bf16(_ptr(packed_bf16), _ptr(pos), _ptr(view_dir), M, _ptr(sigma),
+                                             _ptr(rgb), _stream()), "nerf_mlp_forward_bf16")
+        if end is not None:
+            end.record()
+    return sigma, rgb
+
+
 def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved, g_sigma, g_rgb):
     """Parameter gradients as one flat tensor in state_dict order."""
     lib = _lib.load()

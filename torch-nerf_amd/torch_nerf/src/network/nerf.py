@@ -37,6 +37,10 @@ class NeRF(nn.Module):
         self._pack_key = None
         self._flat = None
         self._packed = None
+        self._packed_bf16 = None
+        # BASELINE configs[2]: set to True to evaluate no-grad fused queries with bf16 weights and
+        # bf16 layer inputs on the bf16 MFMA path (fp32 accumulate).  Training always runs in fp32.
+        self.bf16_inference = False
 
     # ------------------------------------------------------------------ parameters -> kernel stream
     def _ordered_params(self):
@@ -60,6 +64,7 @@ class NeRF(nn.Module):
             with torch.no_grad():
                 self._flat = torch.cat([p.detach().reshape(-1) for p in params]).float().contiguous()
                 self._packed = ops.mlp_pack(self._flat)
+                self._packed_bf16 = None
             self._pack_key = key
         return params, self._flat, self._packed
 
@@ -92,6 +97,10 @@ class NeRF(nn.Module):
     def forward_fused(self, points: torch.Tensor, view_dirs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """points, view_dirs (M,3) RAW: positional encoding happens inside the kernel."""
         params, flat, packed = self._stream()
+        if self.bf16_inference and not self._wants_grad(params):
+            if self._packed_bf16 is None:
+                self._packed_bf16 = ops.mlp_pack_bf16(flat)
+            return ops.mlp_forward_bf16(self._packed_bf16, points, view_dirs)
         return ops.NerfMLPFunction.apply(points, view_dirs, False, self._wants_grad(params), packed, flat, *params)
 
     pos_dim = property(lambda self: self._pos_dim)
