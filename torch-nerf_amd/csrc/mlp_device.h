@@ -105,12 +105,12 @@ struct Pipe {
 };
 
 // acc[fb] += W[32 fb .. 32 fb + 31][32 k-values of this chunk] . b   for NFB feature blocks.
-// If FIRST_PIECE >= 0, the wave also issues 8 LDS-DMA pieces of the next pair, one per q/fb group
-// position, interleaved with the MFMAs.
-template <int NFB, int FIRST_PIECE = -1>
+// If N_PIECES > 0, the wave also issues LDS-DMA pieces FIRST_PIECE .. FIRST_PIECE + N_PIECES - 1 of
+// the next pair, evenly interleaved with the MFMA groups of this chunk.
+template <int NFB, int FIRST_PIECE = 0, int N_PIECES = 0>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, const char *chunk,
                                           const int (&offq)[4], const Pipe *pipe = nullptr) {
-    constexpr int GROUPS = 4 * NFB, EVERY = GROUPS / 8;
+    constexpr int GROUPS = 4 * NFB, EVERY = N_PIECES > 0 ? GROUPS / N_PIECES : 1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -118,19 +118,21 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, con
             const f32x4 a = *reinterpret_cast<const f32x4 *>(chunk + fb * 4096 + offq[q]);
             acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * q + 0], acc[fb], 0, 0, 0);
             acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * q + 1], acc[fb], 0, 0, 0);
-            if (FIRST_PIECE >= 0 && (q * NFB + fb) % EVERY == 0) pipe->issue_piece(FIRST_PIECE + (q * NFB + fb) / EVERY);
+            if (N_PIECES > 0 && (q * NFB + fb) % EVERY == 0) pipe->issue_piece(FIRST_PIECE + (q * NFB + fb) / EVERY);
             acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * q + 2], acc[fb], 0, 0, 0);
             acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * q + 3], acc[fb], 0, 0, 0);
         }
     }
 }
 
-// one pipeline step: both chunks of the acquired pair, with the next pair's copy folded in
+// One pipeline step: both chunks of the acquired pair.  The next pair's 16 DMA pieces are all
+// issued during the FIRST chunk, so the youngest of them still has a whole chunk of MFMAs
+// (8 k cycles) to land before the next acquire waits for it.
 template <int NFB>
 __device__ __forceinline__ void mma_pair(f32x16 (&acc)[8], const f32x16 &b0, const f32x16 &b1, const char *w,
                                          const int (&offq)[4], Pipe &pipe) {
-    mma_chunk<NFB, 0>(acc, b0, w, offq, &pipe);
-    mma_chunk<NFB, 8>(acc, b1, w + CHUNK_BYTES, offq, &pipe);
+    mma_chunk<NFB, 0, 16>(acc, b0, w, offq, &pipe);
+    mma_chunk<NFB>(acc, b1, w + CHUNK_BYTES, offq);
     pipe.issue_done();
 }
 

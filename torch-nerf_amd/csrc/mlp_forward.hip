@@ -154,9 +154,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
                 mma_pair<4>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
             }
             w = lds + pipe.acquire();  // direction chunk + filler chunk (not multiplied)
-            mma_chunk<4, 0>(acc, de, w, offq, &pipe);
-#pragma unroll
-            for (int p = 8; p < 16; ++p) pipe.issue_piece(p);
+            mma_chunk<4, 0, 16>(acc, de, w, offq, &pipe);
             pipe.issue_done();
         }
         sigma_pre += __shfl_xor(sigma_pre, 32, WAVE);
