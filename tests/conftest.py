@@ -17,6 +17,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """libnerf_amd.so is built in-tree once per session (hipcc cross-compiles without a GPU)."""
+    from torch_nerf.amd import _lib
+    _lib.build()
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):
