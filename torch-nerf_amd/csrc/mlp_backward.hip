@@ -84,7 +84,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 
         f32x16 acc[8], act[8];
 
+        // Every stage below acquires its first weight pair BEFORE the vector-ALU section that
+        // produces its inputs (mask, gradient-plane stores): the stores then have a whole pair of
+        // MFMAs to drain before the next acquire's vmcnt(0) would wait for them.
+
         // ---- dY9 = (W_out^T d y10) . [h9 > 0]   (vector ALU, 3 x 128 MACs per sample)
+        const char *w = lds + pipe.acquire();
         {
             const u32x4 mk = masks[(int64_t)8 * MP * 2 + 2 * m + h];
 #pragma unroll
@@ -109,26 +114,34 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            const char *w = lds + pipe.acquire();
-            mma_pair<8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
-        }
-#pragma unroll
-        for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];  // fc_8 has no ReLU
-        save_plane<8>(dy + dy_plane(MP, 8), 256, m, h, act);
-        if (h == 0) dy[dsig_plane(MP) + m] = dsig;
+        mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
+        w = lds + pipe.acquire();
+        mma_pair<8>(acc, act[2], act[3], w, offq, pipe);
 
         // ---- l = 8 .. 1:  dY(l-1) = (W_l^T dY(l)) . [h(l-1) > 0]
         for (int l = 8; l >= 1; --l) {
+            w = lds + pipe.acquire();
+            // finish the previous stage: its accumulators are dY(l) before masking
+            if (l == 8) {
+#pragma unroll
+                for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];  // fc_8 has no ReLU
+                if (h == 0) dy[dsig_plane(MP) + m] = dsig;
+            } else {
+                const u32x4 mk = masks[(int64_t)l * MP * 2 + 2 * m + h];
+#pragma unroll
+                for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) act[fb][r] = mask_bit(mk, fb, r) ? acc[fb][r] : 0.0f;
+            }
+            save_plane<8>(dy + dy_plane(MP, l), 256, m, h, act);
             if (l == 8) {  // the density row of fc_8 contributes w8[0, k] * d y8[0]
 #pragma unroll
                 for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 w = *reinterpret_cast<const f32x4 *>(cb + CB_W8ROW0 + 32 * fb + 8 * q + 4 * h);
+                        const f32x4 wv = *reinterpret_cast<const f32x4 *>(cb + CB_W8ROW0 + 32 * fb + 8 * q + 4 * h);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[fb][4 * q + j] = w[j] * dsig;
+                        for (int j = 0; j < 4; ++j) acc[fb][4 * q + j] = wv[j] * dsig;
                     }
             } else {
 #pragma unroll
@@ -136,17 +149,21 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
             }
+            mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                const char *w = lds + pipe.acquire();
+            for (int pr = 1; pr < 4; ++pr) {
+                w = lds + pipe.acquire();
                 mma_pair<8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
             }
-            const u32x4 mk = masks[(int64_t)(l - 1) * MP * 2 + 2 * m + h];
+        }
+        // ---- dY0: mask with h0 and store (no further propagation: the encodings carry no gradient)
+        {
+            const u32x4 mk = masks[2 * m + h];
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) act[fb][r] = mask_bit(mk, fb, r) ? acc[fb][r] : 0.0f;
-            save_plane<8>(dy + dy_plane(MP, l - 1), 256, m, h, act);
+            save_plane<8>(dy + dy_plane(MP, 0), 256, m, h, act);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

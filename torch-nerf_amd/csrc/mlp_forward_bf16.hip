@@ -50,12 +50,14 @@ struct StepPipe {
     }
 };
 
-// acc[cb][fb] (+)= W[32 fb.., 32 k of this chunk] . B   for both column blocks; b[cb][s] are the two
-// k-steps (16 features each) of the 32-feature input block.  PIECE0 >= 0: issue DMA pieces
-// PIECE0 .. PIECE0+3 of the next step, spread over the chunk.
-template <int NFB, int PIECE0>
+// acc[cb][fb] += W[32 fb.., 32 k of this chunk] . B   for every column block; b[cb][s] are the two
+// k-steps (16 features each) of the 32-feature input block.  N_PIECES > 0: also issue DMA pieces
+// 0 .. N_PIECES-1 of the next step, evenly spread over the (s, fb) groups of this chunk.
+template <int NFB, int N_PIECES>
 __device__ __forceinline__ void mma_chunk16(f32x16 (&acc)[NCB][8], const bf16x8 (&b)[NCB][2], const char *chunk,
                                             const int (&offs)[2], const StepPipe &pipe) {
+    constexpr int GROUPS = 2 * NFB, EVERY = N_PIECES > 0 ? GROUPS / N_PIECES : 1;
+    static_assert(N_PIECES == 0 || GROUPS % N_PIECES == 0, "pieces must divide the groups");
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -64,11 +66,8 @@ __device__ __forceinline__ void mma_chunk16(f32x16 (&acc)[NCB][8], const bf16x8 
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
                 acc[cb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[cb][s], acc[cb][fb], 0, 0, 0);
-            if (PIECE0 >= 0 && (s * NFB + fb) % (NFB / 2) == 0) pipe.issue_piece(PIECE0 + (s * NFB + fb) / (NFB / 2));
+            if (N_PIECES > 0 && (s * NFB + fb) % EVERY == 0) pipe.issue_piece((s * NFB + fb) / EVERY);
         }
-        // keep the scheduler from hoisting every A-fragment load of the step to its top: at most
-        // one k-step's worth (NFB x 4 VGPRs) is in flight, the accumulators already fill the AGPRs
-        // __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -180,10 +179,10 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_bf16_kernel(const char *__
         // a 64-KiB step of which only the first two chunks are multiplied (the encoded position)
         auto position_step = [&](const bf16x8 (&pe)[2][NCB][2]) {
             const char *w = lds + pipe.acquire();
-            mma_chunk16<8, 0>(acc, pe[0], w, offs, pipe);
-            mma_chunk16<8, 4>(acc, pe[1], w + B16_CHUNK_BYTES, offs, pipe);
-#pragma unroll
-            for (int p = 8; p < 16; ++p) pipe.issue_piece(p);
+            // the whole next step is requested during the first chunk: its youngest piece still has
+            // three chunks' worth of MFMAs to land before the next acquire
+            mma_chunk16<8, 16>(acc, pe[0], w, offs, pipe);
+            mma_chunk16<8, 0>(acc, pe[1], w + B16_CHUNK_BYTES, offs, pipe);
             pipe.issue_done();
         };
         // activation of a finished 256-wide layer -> packed bf16 inputs of the next one; then the
@@ -232,10 +231,10 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_bf16_kernel(const char *__
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const char *w = lds + pipe.acquire();
-                mma_chunk16<8, 0>(acc, act[4 * st], w, offs, pipe);
-                mma_chunk16<8, 4>(acc, act[4 * st + 1], w + B16_CHUNK_BYTES, offs, pipe);
-                mma_chunk16<8, 8>(acc, act[4 * st + 2], w + 2 * B16_CHUNK_BYTES, offs, pipe);
-                mma_chunk16<8, 12>(acc, act[4 * st + 3], w + 3 * B16_CHUNK_BYTES, offs, pipe);
+                mma_chunk16<8, 16>(acc, act[4 * st], w, offs, pipe);
+                mma_chunk16<8, 0>(acc, act[4 * st + 1], w + B16_CHUNK_BYTES, offs, pipe);
+                mma_chunk16<8, 0>(acc, act[4 * st + 2], w + 2 * B16_CHUNK_BYTES, offs, pipe);
+                mma_chunk16<8, 0>(acc, act[4 * st + 3], w + 3 * B16_CHUNK_BYTES, offs, pipe);
                 pipe.issue_done();
             }
         }
@@ -245,10 +244,15 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_bf16_kernel(const char *__
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const char *w = lds + pipe.acquire();
-            mma_chunk16<4, 0>(acc, act[4 * st], w, offs, pipe);
-            mma_chunk16<4, 4>(acc, act[4 * st + 1], w + B16_CHUNK_BYTES, offs, pipe);
-            mma_chunk16<4, 8>(acc, act[4 * st + 2], w + 2 * B16_CHUNK_BYTES, offs, pipe);
-            mma_chunk16<4, 12>(acc, act[4 * st + 3], w + 3 * B16_CHUNK_BYTES, offs, pipe);
+            mma_chunk16<4, 8>(acc, act[4 * st], w, offs, pipe);
+            {   // pieces 8..15 ride on the second chunk
+                StepPipe second = pipe;
+                second.src_lane += 8 * 1024;
+                second.lds_wave += 8 * 1024;
+                mma_chunk16<4, 8>(acc, act[4 * st + 1], w + B16_CHUNK_BYTES, offs, second);
+            }
+            mma_chunk16<4, 0>(acc, act[4 * st + 2], w + 2 * B16_CHUNK_BYTES, offs, pipe);
+            mma_chunk16<4, 0>(acc, act[4 * st + 3], w + 3 * B16_CHUNK_BYTES, offs, pipe);
             pipe.issue_done();
         }
         {
@@ -260,9 +264,9 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_bf16_kernel(const char *__
                 encoding_frags(F, 0, h, de[cb]);
             }
             const char *w = lds + pipe.acquire();
-            mma_chunk16<4, 0>(acc, de, w, offs, pipe);
+            mma_chunk16<4, 8>(acc, de, w, offs, pipe);
 #pragma unroll
-            for (int p = 4; p < 16; ++p) pipe.issue_piece(p);
+            for (int p = 8; p < 16; ++p) pipe.issue_piece(p);
             pipe.issue_done();
         }
 
