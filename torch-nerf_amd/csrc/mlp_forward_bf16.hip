@@ -21,6 +21,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // column blocks (of 32 samples) per wavefront.  2 would halve LDS reads and the weight stream per
 // sample, but 256 accumulators + 128 activation registers do not fit without spilling (hipcc 7.2).
+// Also tried: 8 wavefronts per workgroup (two per SIMD, 256 registers each, one wave's vector work
+// under the other's MFMAs): hipcc's schedule of the unrolled step needs ~550 registers and spills
+// ~300 under that budget, whatever sched_barrier placement -- it needs a hand-scheduled step.
 constexpr int NCB = 1;
 constexpr int TILE = 128 * NCB;  // samples per workgroup pass
 
