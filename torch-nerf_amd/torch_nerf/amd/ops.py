@@ -329,8 +329,17 @@ class CompositeFunction(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- fused pass
-def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, u2=None, u3=None):
-    """One inference render_scene pass as a single enqueue -> (rgb (n,3), weights (n,S))."""
+def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, u2=None, u3=None, bf16=False):
+    """One inference render_scene pass as a single enqueue -> (rgb (n,3), weights (n,S)).
+    bf16=True: `packed` is a mlp_pack_bf16 stream and the MLP runs on the bf16 MFMA path."""
+    if bf16:
+        if weights is None:
+            pts, dirs, delta = sample_stratified(ray_o, ray_d, t_bins, partition_size, u1)
+        else:
+            pts, dirs, delta = sample_hierarchical(ray_o, ray_d, t_bins, partition_size, weights, u1, u2, u3)
+        n, S = delta.shape
+        sigma, rgb = mlp_forward_bf16(packed, pts.view(n * S, 3), dirs.view(n * S, 3))
+        return composite_forward(sigma.view(n, S), rgb.view(n, S, 3), delta)
     lib = _lib.load()
     ray_o, ray_d, t_bins, u1 = _gpu(ray_o, "ray_o"), _gpu(ray_d, "ray_d"), _gpu(t_bins, "t_bins"), _gpu(u1, "u1")
     n, Sc = u1.shape

@@ -106,7 +106,8 @@ def allreduce_gradients(parameters, group: Optional[dist.ProcessGroup] = None, a
 
 @torch.no_grad()
 def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, project_to_ndc: bool, seed: int,
-                 group: Optional[dist.ProcessGroup] = None, rays_per_launch: int = 65536) -> torch.Tensor:
+                 group: Optional[dist.ProcessGroup] = None, rays_per_launch: int = 65536,
+                 bf16: bool = False) -> torch.Tensor:
     """Full frame (H*W, 3) on every rank; each rank renders only its pixel range on its own GPU."""
     from torch_nerf.amd import ops
     from torch_nerf.src.renderer.ray_samplers import StratifiedSampler
@@ -118,15 +119,17 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
     lo, hi = shard_range(total, rank, world)
     sampler = StratifiedSampler()
     t_bins, ps = sampler._create_t_bins(camera.t_near, camera.t_far, n_coarse, device)
-    _, _, packed_c = coarse_net._stream()
-    _, _, packed_f = fine_net._stream()
+    _, flat_c, packed_c = coarse_net._stream()
+    _, flat_f, packed_f = fine_net._stream()
+    if bf16:  # BASELINE configs[2]: bf16 weights / layer inputs on the bf16 MFMA path
+        packed_c, packed_f = ops.mlp_pack_bf16(flat_c), ops.mlp_pack_bf16(flat_f)
     out = torch.empty((hi - lo, 3), dtype=torch.float32, device=device)
     for first in range(lo, hi, rays_per_launch):
         n = min(rays_per_launch, hi - first)
         bundle = sampler.generate_rays_from_pixels(camera, project_to_ndc, first=first, count=n, device=device)
         u1c, u1, u2, u3 = ray_draws(seed, first, n, n_coarse, n_fine, device)
-        _, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c)
+        _, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, bf16=bf16)
         rgb, _ = ops.render_rays(packed_f, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1, weights=w, u2=u2,
-                                 u3=u3)
+                                 u3=u3, bf16=bf16)
         out[first - lo: first - lo + n] = rgb
     return gather_image(out, total, group)
