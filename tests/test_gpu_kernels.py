@@ -176,6 +176,26 @@ def test_mlp_forward_ragged_vs_oracle(oracle, ops, M):
     np.testing.assert_allclose(rgb.cpu().numpy()[sub], ro, rtol=0, atol=1e-5)
 
 
+def test_mlp_forward_huge_coordinates_take_the_exact_path(oracle, ops):
+    """|2^9 x| beyond the Cody-Waite range: the kernel switches the whole tile to library sin/cos."""
+    rng = np.random.RandomState(4)
+    M = 300
+    pts = rng.uniform(-2000, 2000, (M, 3)).astype(np.float32)
+    pts[:150] = rng.uniform(-4, 4, (150, 3))          # tiles mixing ordinary and huge samples
+    dirs = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    flat = synth.nerf_flat_params(seed=9, sigma_bias=0.5, sigma_gain=20.0)
+    sigma, rgb = ops.mlp_forward(ops.mlp_pack(dev(flat)), dev(pts), dev(dirs), encoded=False)
+    so, ro = oracle.mlp_forward(flat, oracle.posenc(pts, 10), oracle.posenc(dirs, 4))
+    s, c = sigma.cpu().numpy(), rgb.cpu().numpy()
+    # ordinary samples sharing a wavefront with huge ones went through the exact path: usual bound
+    np.testing.assert_allclose(s[:150], so[:150], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(c[:150], ro[:150], rtol=0, atol=1e-5)
+    # raw coordinates of 2e3 enter fc_in / fc_5 directly: activations are ~1e3x larger and so is the
+    # fp32 summation-order noise; a wrong range reduction would be off by O(1), not O(1e-4)
+    np.testing.assert_allclose(s[150:], so[150:], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(c[150:], ro[150:], rtol=0, atol=2e-3)
+
+
 def test_render_rays_end_to_end_golden(golden, ops):
     """Coarse + fine pass on the reference's own draws: pixel colours within 1e-5."""
     g = golden("f7_e2e")

@@ -10,9 +10,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // sin and cos with a 3-term Cody-Waite reduction (FMA) and Cephes minimax polynomials:
-// <= ~1.5e-7 abs error for |x| < 3e4; larger arguments take the library path.
+// <= ~1.5e-7 abs error for |x| < 3e4.  Branch-free so that the compiler can interleave the 48
+// independent evaluations of a tile; EXACT selects the library path (correct for any argument).
+template <bool EXACT>
 __device__ __forceinline__ void sincos_cw(float x, float &s, float &c) {
-    if (__builtin_expect(fabsf(x) > 30000.0f, 0)) {
+    if (EXACT) {
         s = sinf(x);
         c = cosf(x);
         return;
@@ -37,6 +39,7 @@ __device__ __forceinline__ void sincos_cw(float x, float &s, float &c) {
 
 // feature k of PositionalEncoder(3, L, include_input=True).encode((x,y,z)); 0 beyond kmax
 // layout (positional_encoder.py:83-88): [x y z | sin(2^0 xyz) cos(2^0 xyz) | sin(2^1 xyz) ...]
+template <bool EXACT>
 __device__ __forceinline__ float enc_feature(int k, float x, float y, float z, int kmax) {
     const int e = k - 3;
     const int f = e / 6;
@@ -44,9 +47,16 @@ __device__ __forceinline__ float enc_feature(int k, float x, float y, float z, i
     const int ch = k < 3 ? k : (r6 >= 3 ? r6 - 3 : r6);
     const float v = ch == 0 ? x : (ch == 1 ? y : z);
     float s, c;
-    sincos_cw(ldexpf(v, f < 0 ? 0 : f), s, c);
+    sincos_cw<EXACT>(ldexpf(v, f < 0 ? 0 : f), s, c);
     const float t = r6 >= 3 ? c : s;
     return k < 3 ? v : (k < kmax ? t : 0.0f);
+}
+
+// largest |argument| the encodings of this sample will see: 2^(L-1) * max|coordinate|
+__device__ __forceinline__ bool encoding_needs_exact(const float (&raw)[6]) {
+    const float p = fmaxf(fmaxf(fabsf(raw[0]), fabsf(raw[1])), fabsf(raw[2]));
+    const float d = fmaxf(fmaxf(fabsf(raw[3]), fabsf(raw[4])), fabsf(raw[5]));
+    return !(ldexpf(p, L_POS - 1) < 30000.0f && ldexpf(d, L_DIR - 1) < 30000.0f);  // also true for NaN
 }
 
 // one 1-KiB piece per instruction: LDS[m0 + lane*16] <- global[src]

@@ -88,14 +88,25 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
                 pe[1][r] = (32 + k < E_POS) ? pos[mc * in_w + 32 + k] : 0.0f;
                 de[r] = (k < E_DIR) ? dir[mc * in_wd + k] : 0.0f;
             }
+        } else if (__builtin_expect(__any(encoding_needs_exact(raw)), 0)) {
+            // some lane of this wave has a huge (or non-finite) coordinate: library sin/cos for the tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+                pe[0][r] = enc_feature<true>(k, raw[0], raw[1], raw[2], E_POS);
+                pe[1][r] = enc_feature<true>(32 + k, raw[0], raw[1], raw[2], E_POS);
+                de[r] = enc_feature<true>(k, raw[3], raw[4], raw[5], E_DIR);
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
-                pe[0][r] = enc_feature(k, raw[0], raw[1], raw[2], E_POS);
-                pe[1][r] = enc_feature(32 + k, raw[0], raw[1], raw[2], E_POS);
-                de[r] = enc_feature(k, raw[3], raw[4], raw[5], E_DIR);
+                pe[0][r] = enc_feature<false>(k, raw[0], raw[1], raw[2], E_POS);
+                pe[1][r] = enc_feature<false>(32 + k, raw[0], raw[1], raw[2], E_POS);
+                de[r] = enc_feature<false>(k, raw[3], raw[4], raw[5], E_DIR);
             }
+        }
+        if (!ENCODED) {
             load_raw(tile + gridDim.x);  // next tile's points: a whole tile of MFMAs hides the latency
         }
 

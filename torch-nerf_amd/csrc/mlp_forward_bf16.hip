@@ -93,7 +93,7 @@ __device__ __forceinline__ void encode_all(float x, float y, float z, float (&F)
     for (int c = 0; c < 3; ++c) {
         F[c] = v[c];
         float s, co;
-        sincos_cw(v[c], s, co);
+        sincos_cw<false>(v[c], s, co);  // |coordinate| itself is the only argument: no large-range issue below 3e4
 #pragma unroll
         for (int f = 0; f < LEVELS; ++f) {
             F[3 + 6 * f + c] = s;
