@@ -117,21 +117,45 @@ struct Pipe {
 // acc[fb] += W[32 fb .. 32 fb + 31][32 k-values of this chunk] . b   for NFB feature blocks.
 // If N_PIECES > 0, the wave also issues LDS-DMA pieces FIRST_PIECE .. FIRST_PIECE + N_PIECES - 1 of
 // the next pair, evenly interleaved with the MFMA groups of this chunk.
+// LDS -> 4 VGPRs, issued by hand so that hipcc cannot sink it back to just before its use (it does,
+// whatever sched_group_barrier says, and then reuses ONE fragment buffer for the whole kernel).
+// The destination is NOT protected by the compiler's waitcnt bookkeeping: every use must sit
+// behind lds_fragments_ready().
+__device__ __forceinline__ f32x4 lds_read_fragment(unsigned lds_addr, int imm_offset) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(imm_offset));
+    return v;
+}
+__device__ __forceinline__ void lds_fragments_ready() {
+    __builtin_amdgcn_sched_barrier(0);  // the previous group's MFMAs stay above the wait (they cover it) ...
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // ... and the consumers of the fragment stay below it
+}
+
 template <int NFB, int FIRST_PIECE = 0, int N_PIECES = 0>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, const char *chunk,
                                           const int (&offq)[4], const Pipe *pipe = nullptr) {
     constexpr int GROUPS = 4 * NFB, EVERY = N_PIECES > 0 ? GROUPS / N_PIECES : 1;
+    // A fragments are fetched one (q, fb) group ahead of the MFMAs that consume them, into two
+    // alternating buffers: a ds_read_b128 issued behind a group's last MFMA returns ~80 cycles
+    // later than the matrix pipe frees up, which with a single buffer costs ~14 idle cycles per group.
+    const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)chunk;
+    unsigned addr[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q) addr[q] = base + (unsigned)offq[q];
+    f32x4 abuf[2];
+    abuf[0] = lds_read_fragment(addr[0], 0);
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(chunk + fb * 4096 + offq[q]);
-            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * q + 0], acc[fb], 0, 0, 0);
-            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * q + 1], acc[fb], 0, 0, 0);
-            if (N_PIECES > 0 && (q * NFB + fb) % EVERY == 0) pipe->issue_piece(FIRST_PIECE + (q * NFB + fb) / EVERY);
-            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * q + 2], acc[fb], 0, 0, 0);
-            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * q + 3], acc[fb], 0, 0, 0);
-        }
+    for (int g = 0; g < GROUPS; ++g) {
+        const int q = g / NFB, fb = g % NFB;
+        lds_fragments_ready();  // abuf[g & 1] has landed
+        if (g + 1 < GROUPS) abuf[(g + 1) & 1] = lds_read_fragment(addr[(g + 1) / NFB], ((g + 1) % NFB) * 4096);
+        const f32x4 a = abuf[g & 1];
+        acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * q + 0], acc[fb], 0, 0, 0);
+        acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * q + 1], acc[fb], 0, 0, 0);
+        if (N_PIECES > 0 && g % EVERY == 0) pipe->issue_piece(FIRST_PIECE + g / EVERY);
+        acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * q + 2], acc[fb], 0, 0, 0);
+        acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * q + 3], acc[fb], 0, 0, 0);
     }
 }
 
