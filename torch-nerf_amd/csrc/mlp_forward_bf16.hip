@@ -56,21 +56,40 @@ struct StepPipe {
 // acc[cb][fb] += W[32 fb.., 32 k of this chunk] . B   for every column block; b[cb][s] are the two
 // k-steps (16 features each) of the 32-feature input block.  N_PIECES > 0: also issue DMA pieces
 // 0 .. N_PIECES-1 of the next step, evenly spread over the (s, fb) groups of this chunk.
+__device__ __forceinline__ bf16x8 lds_read_fragment16(unsigned lds_addr, int imm_offset) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(imm_offset));
+    return v;
+}
+
 template <int NFB, int N_PIECES>
 __device__ __forceinline__ void mma_chunk16(f32x16 (&acc)[NCB][8], const bf16x8 (&b)[NCB][2], const char *chunk,
                                             const int (&offs)[2], const StepPipe &pipe) {
     constexpr int GROUPS = 2 * NFB, EVERY = N_PIECES > 0 ? GROUPS / N_PIECES : 1;
     static_assert(N_PIECES == 0 || GROUPS % N_PIECES == 0, "pieces must divide the groups");
+    // A fragments two groups ahead in three rotating buffers (a bf16 MFMA lasts only 32 cycles, an LDS
+    // read ~100): hand-issued reads, see lds_read_fragment in mlp_device.h
+    const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)chunk;
+    const unsigned addr[2] = {base + (unsigned)offs[0], base + (unsigned)offs[1]};
+    bf16x8 abuf[4];
+    abuf[0] = lds_read_fragment16(addr[0], 0);
+    abuf[1] = lds_read_fragment16(addr[1 / NFB], (1 % NFB) * 2048);
+    abuf[2] = lds_read_fragment16(addr[2 / NFB], (2 % NFB) * 2048);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int g = 0; g < GROUPS; ++g) {
+        const int s = g / NFB, fb = g % NFB;
+        // wait until at most the two younger reads are outstanding: fragment g has landed
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < GROUPS) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if (g + 1 < GROUPS) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 3 < GROUPS) abuf[(g + 3) & 3] = lds_read_fragment16(addr[(g + 3) / NFB], ((g + 3) % NFB) * 2048);
+        const bf16x8 a = abuf[g & 3];
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(chunk + fb * 2048 + offs[s]);
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-                acc[cb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[cb][s], acc[cb][fb], 0, 0, 0);
-            if (N_PIECES > 0 && (s * NFB + fb) % EVERY == 0) pipe.issue_piece((s * NFB + fb) / EVERY);
-        }
+        for (int cb = 0; cb < NCB; ++cb)
+            acc[cb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[cb][s], acc[cb][fb], 0, 0, 0);
+        if (N_PIECES > 0 && g % EVERY == 0) pipe.issue_piece(g / EVERY);
     }
 }
 
