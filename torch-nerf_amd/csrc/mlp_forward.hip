@@ -9,11 +9,14 @@
 //    their 256 activations in registers (128 VGPRs) through all layers, transposed
 //    GEMM  Y^T = W X^T  on v_mfma_f32_32x32x2_f32: the D fragment of one layer IS the
 //    B fragment of the next -- activations never touch LDS or HBM
-//  * weights stream L2 -> LDS through a 4-slot ring of 32-KiB chunks filled by LDS-DMA
-//    (global_load_lds_dwordx4, one 64-KiB pair of chunks in flight while the previous pair is
-//    consumed: one vmcnt wait + one s_barrier per 256 MFMAs), shared by the 4 wavefronts; A fragments come out of LDS with conflict-free
-//    ds_read_b128 (XOR-swizzled rows)
-//  * positional encodings are computed in registers straight into B-fragment layout
+//  * weights stream L2 -> LDS through a ring of two 64-KiB PAIRS of 32-KiB chunks filled by LDS-DMA
+//    (global_load_lds_dwordx4): while one pair is consumed (256 MFMAs per wave) the next is in
+//    flight, its 16 DMA instructions per wave folded between the MFMAs of the pair's first chunk;
+//    one vmcnt wait + one s_barrier per pair, shared by the 4 wavefronts
+//  * A fragments come out of LDS with conflict-free ds_read_b128 (XOR-swizzled rows), hand-issued
+//    one group ahead into two alternating register buffers
+//  * positional encodings are computed in registers straight into B-fragment layout (branch-free
+//    Cody-Waite sincos; a wave-uniform test sends tiles with huge coordinates to the library path)
 //  * bound: fp32 MFMA (9280 MFMAs = 38.0 MFLOP per 32 samples); HBM traffic 40 B/sample
 #include "common.h"
 #include "mlp_device.h"
