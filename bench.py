@@ -298,16 +298,28 @@ def main():
                    "parallelism": f"ray-shard x{world}" + (" + all-gather" if world > 1 else "")},
         "roofline": roofline,
     }
+    # secondary legs never take the headline line down with them
+    def guarded(name, fn):
+        try:
+            return fn()
+        except Exception as exc:  # noqa: BLE001
+            return {"error": f"{type(exc).__name__}: {exc}"[:300], "leg": name}
+
     if world == 1 and not args.no_bf16:
-        result["bf16"] = bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank, args.steps, 3)
+        result["bf16"] = guarded("bf16", lambda: bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank,
+                                                          args.steps, 3))
     if world == 1 and not args.no_train:
-        result["train"] = train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank,
-                                    max(3, args.steps // 4), 2)
+        result["train"] = guarded("train", lambda: train_leg(renderer, scene_c, scene_f, nets, pix, device,
+                                                             local_rank, max(3, args.steps // 4), 2))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, quality = cpu_baseline(flats, focal, pose, device)
-        result["cpu_baseline"] = base
-        result.update(quality)
-        result["speedup_vs_cpu_baseline"] = result["value"] / base["value"]
+        out = guarded("cpu_baseline", lambda: cpu_baseline(flats, focal, pose, device))
+        if isinstance(out, tuple):
+            base, quality = out
+            result["cpu_baseline"] = base
+            result.update(quality)
+            result["speedup_vs_cpu_baseline"] = result["value"] / base["value"]
+        else:
+            result["cpu_baseline"] = out
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
