@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Audit hand-issued LDS reads in the compiled kernels (guide section 5.7 item 1/4).
+
+For every inline-asm `ds_read_b128 v[a:b], ...` (between ;;#ASMSTART / ;;#ASMEND) check that no
+instruction READS or WRITES a register of v[a:b] before a later `s_waitcnt lgkmcnt(N)` that covers
+the load (N small enough given the hand-issued reads issued after it).  Usage:
+    hipcc ... -save-temps -c kernel.hip ;  python scripts/audit_asm_loads.py kernel-hip-amdgcn-*.s
+"""
+import re
+import sys
+
+
+def regs(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def audit(path):
+    lines = open(path).read().splitlines()
+    in_asm = False
+    pending = []  # [regset, line_no, younger_asm_reads]
+    problems = 0
+    total = 0
+    for no, raw in enumerate(lines, 1):
+        ln = raw.strip()
+        if ln.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if ln.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not ln or ln.startswith(";") or ln.startswith(".") or ln.endswith(":"):
+            continue
+        op, _, rest = ln.partition(" ")
+        toks = [t.strip().rstrip(",") for t in re.split(r"[ ,]+", rest) if t.strip()]
+        if op.startswith("ds_"):           # every LDS operation is a younger LGKM op for the pending reads
+            for p in pending:
+                p[2] += 1
+            if in_asm and op == "ds_read_b128":
+                pending.append([regs(toks[0]), no, 0])
+                total += 1
+            continue
+        m = re.search(r"lgkmcnt\((\d+)\)", ln)
+        if op == "s_waitcnt" and m:
+            n = int(m.group(1))
+            # LDS returns in order: after the wait at most the n youngest operations are outstanding
+            pending = [p for p in pending if p[2] < n]
+            continue
+        touched = set()
+        for t in toks:
+            touched |= regs(t)
+        for p in pending:
+            if touched & p[0]:
+                problems += 1
+                print(f"{path}:{no}: `{ln[:70]}` touches v{sorted(touched & p[0])} of the un-waited read at line {p[1]}")
+    print(f"{path}: {total} hand-issued ds_read_b128, {problems} problems")
+    return problems
+
+
+if __name__ == "__main__":
+    sys.exit(1 if sum(audit(p) for p in sys.argv[1:]) else 0)
