@@ -147,6 +147,17 @@ int nerf_render_rays(const void *packed, const float *ray_o, const float *ray_d,
                      const float *u1, const float *u2, const float *u3, float *rgb,
                      float *weights_out, void *workspace, nerf_stream_t stream);
 
+/* ---- f1: one torch.optim.Adam step as the reference configures it -- Adam(params, lr, eps) with
+ * default betas, no weight decay, no amsgrad (R/../runners/runner_utils.py:691-695), stepped once per
+ * batch (R/../runners/train.py:216) -- over ONE flat blob (both networks).  `step` counts from 1;
+ * `lr` is the current (scheduler-decayed, runner_utils.py:701-711) rate, a host scalar; grads are
+ * multiplied by grad_scale first (1/world after a data-parallel SUM all-reduce, else 1).
+ * params, exp_avg, exp_avg_sq are updated in place; the four blobs share one 16-byte phase
+ * (address mod 16), e.g. the same element offset into four aligned arenas. */
+int nerf_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                   int64_t step, double lr, double beta1, double beta2, double eps, double grad_scale,
+                   nerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

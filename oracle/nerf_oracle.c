@@ -572,3 +572,44 @@ ORC_API void orc_composite_backward(const float *sigma, const float *radiance, c
         free(wv);
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* f1: optimizer step.  The reference builds                           */
+/*   torch.optim.Adam(params, lr=init_lr, eps=eps)                     */
+/* (runners/runner_utils.py:691-695; default betas, no weight decay,   */
+/* no amsgrad) and calls optimizer.step() once per batch               */
+/* (runners/train.py:216).  The arithmetic is torch's (third party,    */
+/* torch 2.10.0 torch/optim/adam.py _single_tensor_adam -- the CPU     */
+/* default), restated in the same operation order; Python-float        */
+/* scalars are rounded to fp32 when they meet an fp32 tensor; bias     */
+/* corrections and step size are host doubles.  lerp_ is a fused       */
+/* multiply-add in ATen's vectorised CPU kernel (aten/src/ATen/native/ */
+/* cpu/LerpKernel.cpp lerp_vec), so m is a tolerance quantity.         */
+/* `step` counts from 1; lr is the scheduler-decayed rate.             */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_adam_step(float *p, const float *g, float *m, float *v, int64_t n, int64_t step,
+                           double lr, double beta1, double beta2, double eps)
+{
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
+    const float bc2_sqrt = (float)sqrt(bc2), epsf = (float)eps, neg_step = (float)(-(lr / bc1));
+    for (int64_t i = 0; i < n; ++i) {
+        m[i] = fmaf(w1, g[i] - m[i], m[i]);
+        v[i] = v[i] * b2 + (w2 * g[i]) * g[i];
+        const float denom = sqrtf(v[i]) / bc2_sqrt + epsf;
+        p[i] = p[i] + neg_step * (m[i] / denom);
+    }
+}
+
+/* ExponentialLR as the reference configures it (runners/runner_utils.py:701-711):          */
+/* gamma = pow(end_lr / init_lr, 1 / num_iter); scheduler.step() after every optimizer step */
+/* (runners/train.py:217-218).  torch's closed form is not used by step(): it multiplies    */
+/* the running lr by gamma each call (torch/optim/lr_scheduler.py ExponentialLR.get_lr).    */
+ORC_API double orc_exponential_lr(double init_lr, double end_lr, int64_t num_iter, int64_t steps_done)
+{
+    const double gamma = pow(end_lr / init_lr, 1.0 / (double)num_iter);
+    double lr = init_lr;
+    for (int64_t i = 0; i < steps_done; ++i) lr = lr * gamma;
+    return lr;
+}

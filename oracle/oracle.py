@@ -33,6 +33,7 @@ def lib():
         _lib = ctypes.CDLL(_SO)
         _lib.orc_aten_sum_lastdim.restype = ctypes.c_float
         _lib.orc_nerf_param_count.restype = ctypes.c_int64
+        _lib.orc_exponential_lr.restype = ctypes.c_double
     return _lib
 
 
@@ -187,6 +188,20 @@ def composite_backward(sigma, radiance, delta, g_rgb, g_w=None):
                                  None if gw is None else _pf(gw), ctypes.c_int64(n),
                                  ctypes.c_int64(S), _pf(gs), _pf(gc))
     return gs, gc
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam.step as configured at runners/runner_utils.py:691-695; in place on p, m, v."""
+    for a in (p, g, m, v):
+        assert a.dtype == np.float32 and a.flags.c_contiguous and a.shape == p.shape
+    lib().orc_adam_step(_pf(p), _pf(g), _pf(m), _pf(v), ctypes.c_int64(p.size), ctypes.c_int64(step),
+                        ctypes.c_double(lr), ctypes.c_double(beta1), ctypes.c_double(beta2), ctypes.c_double(eps))
+
+
+def exponential_lr(init_lr, end_lr, num_iter, steps_done):
+    """ExponentialLR as configured at runners/runner_utils.py:701-711, after `steps_done` scheduler steps."""
+    return float(lib().orc_exponential_lr(ctypes.c_double(init_lr), ctypes.c_double(end_lr),
+                                          ctypes.c_int64(num_iter), ctypes.c_int64(steps_done)))
 
 
 def render_rays(params, o, d, t_bins, ps, u1, weights=None, u2=None, u3=None, L_pos=10, L_dir=4):

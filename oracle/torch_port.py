@@ -88,7 +88,9 @@ def render_pass(p, o, d, near, far, n_coarse, u1, weights=None, u2=None, u3=None
     n, s, _ = pts.shape
     sigma, rgb = mlp(p, encode(pts.reshape(n * s, 3), 10), encode(dirs.reshape(n * s, 3), 4))
     pix, w = integrate(sigma.reshape(n, s), rgb.reshape(n, s, 3), delta)
-    return pix, w, idx
+    # the reference returns torch.cat over its ray batches (volume_renderer.py:256-259): a NEW tensor, which is
+    # why the fine pass may then do `weights += 1e-5` in place without invalidating the coarse graph
+    return torch.cat([pix], 0), torch.cat([w], 0), idx
 
 
 def render_batch(p_coarse, p_fine, pix, height, width, focal, pose, near, far, n_coarse, n_fine, draws):

@@ -314,6 +314,50 @@ def f7_e2e():
     save("f7_e2e", **out)
 
 
+# ---------------------------------------------------------------- F8 optimizer step (row f1)
+def f8_adam():
+    """The optimizer exactly as runners/runner_utils.py:691-711 builds it and runners/train.py:215-218
+    steps it.  runner_utils itself is not importable here (hydra/omegaconf absent), so the fixture makes
+    the same two constructor calls on torch's own classes with the values of configs/train_params/nerf.yaml
+    (num_iter shortened so that the decay is visible in 8 steps)."""
+    rng = np.random.RandomState(41)
+    init_lr, end_lr, num_iter, eps = 0.0005, 0.00005, 12, 1e-8
+    shapes = [(37, 27), (4,)]                      # 1003 values: exercises the n % 4 tail
+    n = sum(int(np.prod(s)) for s in shapes)
+    p0 = rng.uniform(-0.2, 0.2, n).astype(np.float32)
+    steps = 8
+    grads = (rng.standard_normal((steps, n)) * np.exp(rng.uniform(-12, 2, (steps, n)))).astype(np.float32)
+    grads[:, ::17] = 0.0                            # parameters that never receive gradient
+    grads[3] = 0.0                                  # a step with an all-zero gradient
+    params, off = [], 0
+    for shp in shapes:
+        k = int(np.prod(shp))
+        params.append(torch.nn.Parameter(torch.from_numpy(p0[off:off + k].copy()).reshape(shp)))
+        off += k
+    optimizer = torch.optim.Adam(params, lr=init_lr, eps=eps)
+    gamma = pow(end_lr / init_lr, 1 / num_iter)
+    scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma)
+    traj, lrs = [], []
+    for s in range(steps):
+        optimizer.zero_grad()
+        off = 0
+        for p in params:
+            p.grad = torch.from_numpy(grads[s, off:off + p.numel()].copy()).reshape(p.shape)
+            off += p.numel()
+        lrs.append(optimizer.param_groups[0]["lr"])
+        optimizer.step()
+        scheduler.step()
+        traj.append(np.concatenate([p.detach().numpy().reshape(-1) for p in params]))
+    m = np.concatenate([optimizer.state[p]["exp_avg"].numpy().reshape(-1) for p in params])
+    v = np.concatenate([optimizer.state[p]["exp_avg_sq"].numpy().reshape(-1) for p in params])
+    save("f8_adam", p0=p0, grads=grads, params=np.stack(traj), exp_avg=m, exp_avg_sq=v,
+         lrs=np.array(lrs, dtype=np.float64), config=np.array([init_lr, end_lr, num_iter, eps], dtype=np.float64),
+         shapes=np.array([int(np.prod(s)) for s in shapes], dtype=np.int64))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    f1_raygen(); f2_coarse(); f3_fine(); f4_posenc(); f5_mlp(); f6_composite(); f7_e2e()
+    every = dict(f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
+                 f8=f8_adam)
+    for name in (sys.argv[1:] or list(every)):      # e.g. `make_golden.py f8` rewrites one fixture
+        every[name]()

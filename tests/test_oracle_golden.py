@@ -129,3 +129,25 @@ def test_end_to_end(golden, oracle):
     f = oracle.render_rays(pf, o, d, t_bins, ps, g["u1"], weights=g["coarse_w"], u2=g["u2"], u3=g["u3"])
     np.testing.assert_allclose(f["rgb"], g["fine_rgb"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(f["weights"], g["fine_w"], rtol=0, atol=1e-5)
+
+
+def test_adam_and_exponential_lr(golden, oracle):
+    """Row f1: the optimizer step (runner_utils.py:691-711, train.py:215-218) against torch.optim.Adam +
+    ExponentialLR driven the reference's way.  The learning-rate sequence is exact (double arithmetic);
+    parameters match to one ulp of the parameter plus 2e-6 of the step taken (ATen's vectorised
+    lerp / sqrt / div roundings are not restated bit for bit)."""
+    g = golden("f8_adam")
+    init_lr, end_lr, num_iter, eps = g["config"]
+    p = g["p0"].copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for s in range(g["grads"].shape[0]):
+        lr = oracle.exponential_lr(init_lr, end_lr, int(num_iter), s)
+        assert lr == g["lrs"][s]
+        before = p.copy()
+        oracle.adam_step(p, np.ascontiguousarray(g["grads"][s]), m, v, s + 1, lr, eps=eps)
+        want = g["params"][s]
+        step_size = np.abs(want - before).max()
+        tol = np.spacing(np.abs(want)) + 2e-6 * step_size
+        assert np.all(np.abs(p - want) <= tol), f"step {s}: {np.abs(p - want).max()}"
+    np.testing.assert_allclose(m, g["exp_avg"], rtol=2e-6, atol=1e-12)
+    np.testing.assert_allclose(v, g["exp_avg_sq"], rtol=2e-6, atol=1e-30)

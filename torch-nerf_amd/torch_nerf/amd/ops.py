@@ -282,6 +282,24 @@ class NerfMLPFunction(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
+# --------------------------------------------------------------------------- optimizer (row f1)
+def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+              step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+              grad_scale: float = 1.0) -> None:
+    """One torch.optim.Adam step (runner_utils.py:691-695 configuration) over flat fp32 blobs, in place."""
+    lib = _lib.load()
+    n = params.numel()
+    for name, t in (("params", params), ("grads", grads), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda):
+            raise RuntimeError(f"adam_step: {name} must live on the GPU: there is no CPU fallback")
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise ValueError(f"adam_step: {name} must be a contiguous fp32 blob of {n} values")
+    with torch.cuda.device(params.device):
+        _lib.check(lib.nerf_adam_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), n, int(step),
+                                      float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
+                                      _stream()), "nerf_adam_step")
+
+
 # --------------------------------------------------------------------------- integrator
 def composite_forward(sigma, radiance, delta):
     lib = _lib.load()

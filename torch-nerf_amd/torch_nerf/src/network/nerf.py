@@ -62,11 +62,30 @@ class NeRF(nn.Module):
             if not params[0].is_cuda:
                 raise RuntimeError("NeRF parameters must be on the GPU: the HIP path has no CPU fallback")
             with torch.no_grad():
-                self._flat = torch.cat([p.detach().reshape(-1) for p in params]).float().contiguous()
+                self._flat = self._blob_view(params)
+                if self._flat is None:
+                    self._flat = torch.cat([p.detach().reshape(-1) for p in params]).float().contiguous()
                 self._packed = ops.mlp_pack(self._flat)
                 self._packed_bf16 = None
             self._pack_key = key
         return params, self._flat, self._packed
+
+    @staticmethod
+    def _blob_view(params):
+        """The 22 tensors as ONE flat fp32 view if they already sit back to back in one storage, in
+        state_dict order (torch_nerf.amd.optim.FusedAdam homes them that way), else None."""
+        first = params[0]
+        if first.dtype != torch.float32:
+            return None
+        nxt, store, total = first.data_ptr(), first.untyped_storage().data_ptr(), 0
+        for p in params:
+            if p.data_ptr() != nxt or p.untyped_storage().data_ptr() != store or not p.is_contiguous():
+                return None
+            nxt += 4 * p.numel()
+            total += p.numel()
+        if first.data_ptr() % 16:
+            return None
+        return first.detach().as_strided((total,), (1,), first.storage_offset())
 
     @staticmethod
     def _wants_grad(params) -> bool:
