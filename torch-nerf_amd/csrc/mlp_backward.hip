@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
     for (int q = 0; q < 4; ++q) offq[q] = chunk_slot_offset(i, 2 * q + h);
 
     Pipe pipe;
-    pipe.src_lane = packed + BWD_OFFSET + wave * 8192 + lane * 16;
+    pipe.src_wave = packed + BWD_OFFSET + wave * 8192;
+    pipe.lane_off = (unsigned)lane * 16u;
     pipe.lds_wave =
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 8192u;
     pipe.issued = 0;
@@ -229,8 +230,9 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
     const bool want_bias = (g.flags & FLAG_BIAS) != 0;
     const int64_t t0 = tiles_total * slice / num_slices;
     const int64_t t1 = tiles_total * (slice + 1) / num_slices;
-    const char *a_src = reinterpret_cast<const char *>(dy + g.a_off) + lane * 16;
-    const char *x_src = reinterpret_cast<const char *>(saved + g.x_off) + lane * 16;
+    const char *a_src = reinterpret_cast<const char *>(dy + g.a_off);      // wave-uniform; the lane offset rides
+    const char *x_src = reinterpret_cast<const char *>(saved + g.x_off);   // in the DMA instruction's vector operand
+    const unsigned lane_off = (unsigned)lane * 16u;
     float *out = partial + g.partial_off + slice * slice_stride(g);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
 
@@ -249,11 +251,11 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
         const char *as = a_src + t * A_BYTES;
         const unsigned ad = lds_base + buf * STAGE_BYTES;
 #pragma unroll
-        for (int j = 0; j < A_PIECES; ++j) lds_dma_16(as + (wave + 4 * j) * 1024, ad + (wave + 4 * j) * 1024);
+        for (int j = 0; j < A_PIECES; ++j) lds_dma_16s(as + (wave + 4 * j) * 1024, lane_off, ad + (wave + 4 * j) * 1024);
         const char *xs = x_src + t * X_BYTES;
         const unsigned xd = ad + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < X_PIECES; ++j) lds_dma_16(xs + (wave + 4 * j) * 1024, xd + (wave + 4 * j) * 1024);
+        for (int j = 0; j < X_PIECES; ++j) lds_dma_16s(xs + (wave + 4 * j) * 1024, lane_off, xd + (wave + 4 * j) * 1024);
     };
 
     // prologue: NSTAGE-1 tiles in flight (tiles past the end are re-reads of the last tile: the

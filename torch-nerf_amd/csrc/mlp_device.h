@@ -59,6 +59,20 @@ __device__ __forceinline__ bool encoding_needs_exact(const float (&raw)[6]) {
     return !(ldexpf(p, L_POS - 1) < 30000.0f && ldexpf(d, L_DIR - 1) < 30000.0f);  // also true for NaN
 }
 
+// one 1-KiB piece per instruction, wave-uniform base + per-lane byte offset:
+// LDS[m0 + lane*16] <- global[src + lane_off].  The address arithmetic of a piece is then scalar (the
+// per-lane form costs a 64-bit vector add per piece, in issue slots the MFMA stream cannot hide) and M0 is
+// simply overwritten: nothing else in these kernels uses it (gfx9+ LDS instructions do not need it).
+__device__ __forceinline__ void lds_dma_16s(const char *src, unsigned lane_off, unsigned lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(lane_off), "s"(src), "s"(lds_dst)
+        : "memory");
+}
+
 // one 1-KiB piece per instruction: LDS[m0 + lane*16] <- global[src]
 __device__ __forceinline__ void lds_dma_16(const char *src, unsigned lds_dst) {
     unsigned keep;
@@ -77,7 +91,8 @@ __device__ __forceinline__ void lds_dma_16(const char *src, unsigned lds_dst) {
 // The ring holds two pairs: while pair p is consumed, pair p+1 is in flight.  Each wave copies its
 // quarter of every chunk (8 one-KiB pieces); completion is per wave (vmcnt) + one workgroup barrier.
 struct Pipe {
-    const char *src_lane;  // stream base + this lane's byte offset inside a chunk
+    const char *src_wave;  // stream base + this wave's byte offset inside a chunk (wave-uniform)
+    unsigned lane_off;     // lane * 16
     unsigned lds_wave;     // LDS byte address of ring slot 0 + this wave's offset
     unsigned issued;       // pairs issued so far
     int issue_pos;         // stream position (in pairs) of the next pair to issue
@@ -87,8 +102,8 @@ struct Pipe {
     // one of the 16 one-KiB pieces this wave copies per pair (piece 0..7 -> chunk 0, 8..15 -> chunk 1)
     __device__ __forceinline__ void issue_piece(int piece) const {
         const int c = piece >> 3, j = piece & 7;
-        lds_dma_16(src_lane + (size_t)issue_pos * PAIR_BYTES + c * CHUNK_BYTES + j * 1024,
-                   lds_wave + (issued & 1) * PAIR_BYTES + c * CHUNK_BYTES + j * 1024);
+        lds_dma_16s(src_wave + (size_t)issue_pos * PAIR_BYTES + c * CHUNK_BYTES + j * 1024, lane_off,
+                    lds_wave + (issued & 1) * PAIR_BYTES + c * CHUNK_BYTES + j * 1024);
     }
     __device__ __forceinline__ void issue_done() {
         ++issued;

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
     for (int q = 0; q < 4; ++q) offq[q] = chunk_slot_offset(i, 2 * q + h);
 
     Pipe pipe;
-    pipe.src_lane = packed + CONST_BYTES + wave * 8192 + lane * 16;
+    pipe.src_wave = packed + CONST_BYTES + wave * 8192;
+    pipe.lane_off = (unsigned)lane * 16u;
     pipe.lds_wave =
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 8192u;
     pipe.issued = 0;

@@ -28,7 +28,8 @@ constexpr int NCB = 1;
 constexpr int TILE = 128 * NCB;  // samples per workgroup pass
 
 struct StepPipe {
-    const char *src_lane;  // stream base + wave * 16 KiB + lane * 16
+    const char *src_wave;  // stream base + wave * 16 KiB (wave-uniform)
+    unsigned lane_off;     // lane * 16
     unsigned lds_wave;     // LDS address of ring slot 0 + wave * 16 KiB
     unsigned issued;
     int issue_pos;
@@ -36,8 +37,8 @@ struct StepPipe {
 
     // piece p (0..15) of the next step: this wave copies a contiguous 16 KiB quarter of the step
     __device__ __forceinline__ void issue_piece(int p) const {
-        lds_dma_16(src_lane + (size_t)issue_pos * B16_STEP_BYTES + p * 1024,
-                   lds_wave + (issued & 1) * B16_STEP_BYTES + p * 1024);
+        lds_dma_16s(src_wave + (size_t)issue_pos * B16_STEP_BYTES + p * 1024, lane_off,
+                    lds_wave + (issued & 1) * B16_STEP_BYTES + p * 1024);
     }
     __device__ __forceinline__ void issue_done() {
         ++issued;
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_bf16_kernel(const char *__
     for (int s = 0; s < 2; ++s) offs[s] = b16_frag_offset(i, 2 * s + h);
 
     StepPipe pipe;
-    pipe.src_lane = packed + CONST_BYTES + wave * 16384 + lane * 16;
+    pipe.src_wave = packed + CONST_BYTES + wave * 16384;
+    pipe.lane_off = (unsigned)lane * 16u;
     pipe.lds_wave = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 16384u;
     pipe.issued = 0;
     pipe.issue_pos = 0;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_bf16_kernel(const char *__
             mma_chunk16<4, 8>(acc, act[4 * st], w, offs, pipe);
             {   // pieces 8..15 ride on the second chunk
                 StepPipe second = pipe;
-                second.src_lane += 8 * 1024;
+                second.src_wave += 8 * 1024;
                 second.lds_wave += 8 * 1024;
                 mma_chunk16<4, 8>(acc, act[4 * st + 1], w + B16_CHUNK_BYTES, offs, second);
             }
