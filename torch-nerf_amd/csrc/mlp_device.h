@@ -59,6 +59,16 @@ __device__ __forceinline__ bool encoding_needs_exact(const float (&raw)[6]) {
     return !(ldexpf(p, L_POS - 1) < 30000.0f && ldexpf(d, L_DIR - 1) < 30000.0f);  // also true for NaN
 }
 
+// ReLU as ONE instruction.  fmaxf(x, 0) on a raw MFMA result compiles to two v_max_f32 (hipcc first
+// canonicalises a value it cannot prove quiet; it folds v_med3(x, 0, inf) back into the same pair), and every
+// vector instruction of a layer seam is exposed: one wavefront per SIMD has no other wave to hide it behind.
+// v_max_f32 itself needs no canonical input (IEEE mode quiets NaNs: NaN -> 0, -0 -> +0, like fmaxf).
+__device__ __forceinline__ float relu1(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
 // one 1-KiB piece per instruction, wave-uniform base + per-lane byte offset:
 // LDS[m0 + lane*16] <- global[src + lane_off].  The address arithmetic of a piece is then scalar (the
 // per-lane form costs a 64-bit vector add per piece, in issue slots the MFMA stream cannot hide) and M0 is
@@ -195,7 +205,7 @@ __device__ __forceinline__ f32x16 finish_block(const f32x16 &raw, const float *b
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float v = raw[4 * q + j] + bv[j];
-            x[4 * q + j] = RELU ? fmaxf(v, 0.0f) : v;
+            x[4 * q + j] = RELU ? relu1(v) : v;
         }
     }
     return x;
@@ -248,7 +258,9 @@ __device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, i
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// ReLU sign bits of a layer: dword fb>>1, bit 16*(fb&1)+r  <-  blk[fb][r] > 0
+// ReLU sign bits of a layer: dword fb>>1, bit 16*(fb&1)+r  <-  blk[fb][r] > 0.  blk is POST-ReLU (>= +0), so
+// "> 0" is "bit pattern != 0": min(bits, 1) shifted into place is two vector instructions per value, where
+// compare + select costs three plus the wait states gfx950 wants between a VCC write and its vector reader.
 template <int NFB>
 __device__ __forceinline__ void save_mask(float *mask_plane, int64_t m, int h, const f32x16 *blk) {
     u32x4 bits = {0u, 0u, 0u, 0u};
@@ -256,7 +268,11 @@ __device__ __forceinline__ void save_mask(float *mask_plane, int64_t m, int h, c
     for (int fb = 0; fb < NFB; ++fb) {
         unsigned w = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) w |= (blk[fb][r] > 0.0f ? 1u : 0u) << r;
+        for (int r = 0; r < 16; ++r) {
+            unsigned t;
+            asm("v_min_u32 %0, 1, %1" : "=v"(t) : "v"(blk[fb][r]));
+            w |= t << r;
+        }
         bits[fb >> 1] |= w << (16 * (fb & 1));
     }
     reinterpret_cast<u32x4 *>(mask_plane)[2 * m + h] = bits;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) act[fb][r] = fmaxf(acc[fb][r], 0.0f);  // ReLU of layer l-1
+                for (int r = 0; r < 16; ++r) act[fb][r] = relu1(acc[fb][r]);  // ReLU of layer l-1
             if (SAVE) {
                 save_plane<8>(saved + pl_h(MP, l - 1), 256, m, h, act);
                 save_mask<8>(saved + pl_masks(MP) + (int64_t)(l - 1) * MP * 8, m, h, act);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[fb][r] = fmaxf(acc[fb][r], 0.0f);
+            for (int r = 0; r < 16; ++r) acc[fb][r] = relu1(acc[fb][r]);
         if (SAVE) {
             save_plane<4>(saved + pl_h9(MP), 128, m, h, acc);
             save_mask<4>(saved + pl_masks(MP) + (int64_t)8 * MP * 8, m, h, acc);

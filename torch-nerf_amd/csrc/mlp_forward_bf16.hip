@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_bf16_kernel(const char *__
                 for (int cb = 0; cb < NCB; ++cb) {
                     f32x16 x;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) x[r] = relu ? fmaxf(acc[cb][fb][r], 0.0f) : acc[cb][fb][r];
+                    for (int r = 0; r < 16; ++r) x[r] = relu ? relu1(acc[cb][fb][r]) : acc[cb][fb][r];
                     if (density) sigma_pre[cb] += block_dot(cb_ + CB_W8ROW0 + 32 * fb, x, h);
                     pack_block(x, act[fb][cb]);
                 }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_bf16_kernel(const char *__
             for (int fb = 0; fb < 4; ++fb) {
                 f32x16 x;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = fmaxf(acc[cb][fb][r], 0.0f);
+                for (int r = 0; r < 16; ++r) x[r] = relu1(acc[cb][fb][r]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) y[c] += block_dot(cb_ + CB_WOUT + c * HALF + 32 * fb, x, h);
             }
