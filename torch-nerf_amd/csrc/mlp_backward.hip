@@ -29,8 +29,13 @@ using namespace mlp;
 // ------------------------------------------------------------------------------------------
 // stage 1: dX chain
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool mask_bit(const u32x4 &mk, int fb, int r) {
-    return (mk[fb >> 1] >> (16 * (fb & 1) + r)) & 1u;
+// v where the ReLU of feature (fb, r) was active, else +0: the mask bit, sign-extended to 0 / ~0 by ONE
+// v_bfe_i32, ANDed onto the value.  (test + compare + select is three instructions per value plus the wait
+// states gfx950 wants between a VCC write and its vector reader, all of it exposed in the layer seam.)
+__device__ __forceinline__ float masked(const u32x4 &mk, int fb, int r, float v) {
+    int keep;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(mk[fb >> 1]), "n"(16 * (fb & 1) + r));
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
 }
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restrict__ packed, int64_t M,
@@ -68,7 +73,17 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
     const int64_t MP = padded_rows(M);
     const u32x4 *masks = reinterpret_cast<const u32x4 *>(saved + pl_masks(MP));
     const int64_t ntiles = MP / TILE_SAMPLES;
+#ifdef X_TIMELINE   // scripts/timeline_dx.py: cycle stamps of workgroup 0, written behind the dY planes
+    // the tail of the dW partial-tile area (sized for 525 slices, about half are used)
+    unsigned long long *tl = reinterpret_cast<unsigned long long *>(
+        dy + (MP * DY_FLOATS_PER_SAMPLE + 255) / 256 * 256 + (int64_t)(2 * 256 + 13) * (256 * 256 + 256) - 65536);
+    int tl_n = 0;
+#define TS() do { if (blockIdx.x == 0 && tid == 0) tl[tl_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TS() do {} while (0)
+#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        TS();
         const int64_t m = tile * TILE_SAMPLES + wave * 32 + i;
         const bool valid = m < M;
         const int64_t mc = valid ? m : M - 1;
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v = fmaf(w2[j], gy[2], fmaf(w1[j], gy[1], w0[j] * gy[0]));
-                        act[fb][4 * q + j] = mask_bit(mk, fb, 4 * q + j) ? v : 0.0f;
+                        act[fb][4 * q + j] = masked(mk, fb, 4 * q + j, v);
                     }
                 }
         }
@@ -120,8 +135,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         mma_pair<8>(acc, act[2], act[3], w, offq, pipe);
 
         // ---- l = 8 .. 1:  dY(l-1) = (W_l^T dY(l)) . [h(l-1) > 0]
+        TS();
         for (int l = 8; l >= 1; --l) {
+            TS();
             w = lds + pipe.acquire();
+            TS();
             // finish the previous stage: its accumulators are dY(l) before masking
             if (l == 8) {
 #pragma unroll
@@ -132,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 #pragma unroll
                 for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) act[fb][r] = mask_bit(mk, fb, r) ? acc[fb][r] : 0.0f;
+                    for (int r = 0; r < 16; ++r) act[fb][r] = masked(mk, fb, r, acc[fb][r]);
             }
             save_plane<8>(dy + dy_plane(MP, l), 256, m, h, act);
             if (l == 8) {  // the density row of fc_8 contributes w8[0, k] * d y8[0]
@@ -150,20 +168,23 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
             }
+            TS();
             mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
+            TS();
 #pragma unroll
             for (int pr = 1; pr < 4; ++pr) {
                 w = lds + pipe.acquire();
                 mma_pair<8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
             }
         }
+        TS();
         // ---- dY0: mask with h0 and store (no further propagation: the encodings carry no gradient)
         {
             const u32x4 mk = masks[2 * m + h];
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) act[fb][r] = mask_bit(mk, fb, r) ? acc[fb][r] : 0.0f;
+                for (int r = 0; r < 16; ++r) act[fb][r] = masked(mk, fb, r, acc[fb][r]);
             save_plane<8>(dy + dy_plane(MP, 0), 256, m, h, act);
         }
     }
@@ -201,6 +222,12 @@ __device__ __forceinline__ int64_t slice_stride(const GemmDesc &g) {
     return (int64_t)g.a_width * g.x_width + SLICE_EXTRA;
 }
 
+__device__ __forceinline__ float lds_read_b32(unsigned lds_addr, int imm_offset) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(imm_offset));
+    return v;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N == 0 || N == 3 || N == 5 || N == 10, "add the immediate below");
@@ -225,6 +252,8 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
     static_assert(NSTAGE * STAGE_BYTES <= DW_LDS_BYTES, "stage ring exceeds the LDS allocation");
     constexpr int PER_WAVE = A_PIECES + X_PIECES;  // DMA instructions per wave per tile
     const int i = lane & 31, h = lane >> 5;
+    const int frag_base = (i >> 3) * 256 + 4 * ((2 * h + ((i >> 2) & 1)) ^ (2 * ((i >> 3) & 1))) + (i & 3);
+    const int frag_swing = 16 * (i >> 4);
     const int64_t tiles_total = MP / 32;
     const int num_slices = g.num_slices;
     const bool want_bias = (g.flags & FLAG_BIAS) != 0;
@@ -272,25 +301,41 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
             if (nb >= NSTAGE) nb -= NSTAGE;
             issue(tn < t1 ? tn : t1 - 1, nb);
         }
-        const float *A = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES) + wave * 32 * NA + i;
-        const float *X = reinterpret_cast<const float *>(lds + buf * STAGE_BYTES + A_BYTES) + i;
+        // Fragments out of the TF-layout tiles (mlp_layout.h): lane (i, h) of k-step s wants sample 2s + h,
+        // feature 32 FB + i, which sits at float FB*1024 + (i>>3)*256 + 16*(s ^ (i>>4)) + 4*((2h + ((i>>2)&1)) ^ (2*((i>>3)&1)))
+        // + (i&3) of its tile: one per-lane base for even and one for odd s, plus compile-time offsets.
+        // The reads are issued by hand one k-step ahead of the MFMAs that consume them (16 MFMAs = 1 k cycles
+        // cover the LDS latency) with the feature block and the k-step in the instruction's 16-bit offset:
+        // left to hipcc they become ds_read2_b32 with an address add each, all at the top of the loop body.
+        const unsigned stage = lds_base + (unsigned)(buf * STAGE_BYTES);
+        const unsigned a_addr[2] = {stage + 4u * (unsigned)(wave * NA * 1024 + frag_base + frag_swing),
+                                    stage + 4u * (unsigned)(wave * NA * 1024 + frag_base - frag_swing)};
+        const unsigned x_addr[2] = {stage + (unsigned)A_BYTES + 4u * (unsigned)(frag_base + frag_swing),
+                                    stage + (unsigned)A_BYTES + 4u * (unsigned)(frag_base - frag_swing)};
+        float a[2][NA], b[2][KB];
+#define DW_FETCH(S)                                                                                   \
+        {                                                                                             \
+            _Pragma("unroll") for (int nb = 0; nb < NA; ++nb)                                         \
+                a[(S) & 1][nb] = lds_read_b32(a_addr[(S) & 1], nb * 4096 + 64 * (S));                 \
+            _Pragma("unroll") for (int kb = 0; kb < KB; ++kb)                                         \
+                b[(S) & 1][kb] = lds_read_b32(x_addr[(S) & 1], kb * 4096 + 64 * (S));                 \
+        }
+        DW_FETCH(0)
         // dW += dY^T X over the 32 samples of the tile: 16 k-steps of 2 samples.  The A fragments
         // (dY values) double as the bias-gradient summands: db[n] = sum over samples of dY[m][n].
-#pragma unroll 4
+#pragma unroll
         for (int s = 0; s < 16; ++s) {
-            float a[NA], b[KB];
-#pragma unroll
-            for (int nb = 0; nb < NA; ++nb) a[nb] = A[(2 * s + h) * AW + 32 * nb];
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) b[kb] = X[(2 * s + h) * XW + 32 * kb];
+            lds_fragments_ready();   // k-step s has landed
+            if (s + 1 < 16) DW_FETCH(s + 1)
 #pragma unroll
             for (int nb = 0; nb < NA; ++nb) {
-                bsum[nb] += a[nb];
+                bsum[nb] += a[s & 1][nb];
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
-                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], b[kb], acc[nb][kb], 0, 0, 0);
+                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][nb], b[s & 1][kb], acc[nb][kb], 0, 0, 0);
             }
         }
+#undef DW_FETCH
         buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     }
     // partial tile of this slice: row-major [AW][XW], then bias[AW]
@@ -362,11 +407,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_vec_kernel(const float *__restric
         for (; m + U <= hi; m += U) {
             float x[U], d[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { x[u] = h7[(m + u) * FEAT + k]; d[u] = dsig[m + u]; }
+            for (int u = 0; u < U; ++u) { x[u] = h7[tf_offset(FEAT, m + u, k)]; d[u] = dsig[m + u]; }
 #pragma unroll
             for (int u = 0; u < U; ++u) { w = fmaf(d[u], x[u], w); b += d[u]; }
         }
-        for (; m < hi; ++m) { const float d = dsig[m]; w = fmaf(d, h7[m * FEAT + k], w); b += d; }
+        for (; m < hi; ++m) { const float d = dsig[m]; w = fmaf(d, h7[tf_offset(FEAT, m, k)], w); b += d; }
         out[k] = w;
         if (k == 0) out[FEAT] = b;
         return;
@@ -380,7 +425,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_vec_kernel(const float *__restric
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t mm = m + 2 * u;
-            x[u] = h9[mm * HALF + k];
+            x[u] = h9[tf_offset(HALF, mm, k)];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float y = rgb[3 * mm + c];
@@ -393,7 +438,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_vec_kernel(const float *__restric
             for (int c = 0; c < 3; ++c) { w[c] = fmaf(gy[u][c], x[u], w[c]); b[c] += gy[u][c]; }
     }
     for (; m < hi; m += 2) {
-        const float x = h9[m * HALF + k];
+        const float x = h9[tf_offset(HALF, m, k)];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float y = rgb[3 * m + c];

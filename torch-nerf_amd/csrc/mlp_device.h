@@ -240,19 +240,25 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[8], const float *bias, i
         }
 }
 
-// row m of a row-major plane <- this lane's 4-feature groups.  Stores are unconditional: rows in
-// [M, MP) receive the (finite) values of the clamped lane.  The backward GEMMs stay exact because
-// the GRADIENT planes hold exact zeros there (upstream gradients of padded lanes are zero), so a
-// padded row contributes 0 * finite = 0 to every sum.
+// Sample m of a TF-layout plane (mlp_layout.h) <- this lane's 4-feature groups: one fully coalesced 1-KiB
+// store per (fb, q) slot.  m - (m & 31) is the same in all lanes of the wavefront, so the tile address is
+// scalar and the per-lane part is four 32-bit offsets.  Stores are unconditional: rows in [M, MP) receive the
+// (finite) values of the clamped lane.  The backward GEMMs stay exact because the GRADIENT planes hold exact
+// zeros there (upstream gradients of padded lanes are zero), so a padded row contributes 0 * finite = 0 to
+// every sum.
 template <int NFB>
 __device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, int h, const f32x16 *blk) {
-    float *row = plane + m * width + 4 * h;
+    const int i = (int)(m & 31);
+    const uint64_t tile_addr = reinterpret_cast<uint64_t>(plane + (m - i) * width);
+    char *tile = reinterpret_cast<char *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(tile_addr >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)tile_addr));
+    const unsigned unit = (unsigned)(2 * i + h);
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
-            *reinterpret_cast<f32x4 *>(row + 32 * fb + 8 * q) = v;
+            *reinterpret_cast<f32x4 *>(tile + (4 * fb + q) * 1024 + ((unit ^ (2u * q)) << 4)) = v;
         }
 }
 

@@ -82,9 +82,18 @@ constexpr int RING_SLOTS = 4;
 constexpr int PAIR_BYTES = 2 * CHUNK_BYTES;
 constexpr int LDS_BYTES = RING_SLOTS * CHUNK_BYTES + CONST_BYTES;  // 144384 <= 160 KiB
 
-// ---- activation record written by the training-mode forward.  All planes are row-major
-// with MP = M rounded up to a multiple of 128 rows so that the backward GEMMs may consume whole
-// 32-row tiles; rows >= M hold finite filler here and exact zeros in the gradient planes.
+// ---- activation record written by the training-mode forward.  MP = M rounded up to a multiple of 128
+// rows so that the backward GEMMs may consume whole 32-row tiles; rows >= M hold finite filler here and
+// exact zeros in the gradient planes.
+// Plane layout "TF" (tile-fragment), shared by the record and by the gradient planes of the dX chain:
+// a plane of W features/sample is a sequence of 32-sample tiles of 32 W contiguous floats -- what the dW
+// kernel DMAs into LDS in one go -- and inside a tile the data sits in the order the WRITER holds it:
+// slot (fb, q) = the 4-feature group {32 fb + 8 q + 4 h + e} of all 32 samples and both lane halves h =
+// 64 lanes x 16 B = exactly the 1 KiB one wavefront store instruction writes, so every store is eight full
+// 128-byte lines (a row-major plane makes the same instruction 32 scattered 32-byte pieces: the layer
+// seams of the dX chain then take 10.4 k cycles instead of 5.4 k).  Inside a slot, lane (i, h) sits at 16-byte
+// unit (2 i + h) ^ (2 q): the XOR makes the dW kernel's ds_read_b32 fragments (one sample pair x 32
+// consecutive features) hit 32 different LDS banks per half-wave.
 //   float planes (offsets in floats, x MP):
 //     PL_PE   : encoded position, 64 floats/sample (63 + one zero)
 //     PL_H(l) : post-ReLU outputs of fc_in (l=0), fc_1 .. fc_7 (l=7), 256 floats/sample
@@ -94,6 +103,10 @@ constexpr int LDS_BYTES = RING_SLOTS * CHUNK_BYTES + CONST_BYTES;  // 144384 <= 
 //   mask planes (after the float planes): 9 planes (h0..h7, h9) of 32 B/sample: for sample m and
 //   lane half h, a uint4 at index 2m+h whose dword fb>>1, bit 16*(fb&1)+r is (activation > 0)
 //   for the D-fragment register r of feature block fb.
+__host__ __device__ constexpr int64_t tf_offset(int width, int64_t m, int k) {  // element (sample m, feature k)
+    return (m >> 5) * 32 * width + (((k >> 5) * 4 + ((k >> 3) & 3)) << 8) +
+           4 * ((2 * (int)(m & 31) + ((k >> 2) & 1)) ^ (2 * ((k >> 3) & 3))) + (k & 3);
+}
 constexpr int SAVED_FLOATS_PER_SAMPLE = 64 + 8 * 256 + 256 + 128 + 32;  // 2528
 constexpr int SAVED_MASK_PLANES = 9;
 constexpr int SAVED_BYTES_PER_SAMPLE = SAVED_FLOATS_PER_SAMPLE * 4 + SAVED_MASK_PLANES * 32;  // 10400
