@@ -250,6 +250,7 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
     // thin X tiles finish their MFMAs faster than one DMA round trip: keep two tiles in flight
     constexpr int NSTAGE = (KB <= 2) ? 3 : 2;
     static_assert(NSTAGE * STAGE_BYTES <= DW_LDS_BYTES, "stage ring exceeds the LDS allocation");
+    static_assert(A_PIECES + X_PIECES <= 16, "one DMA piece per k-step");
     constexpr int PER_WAVE = A_PIECES + X_PIECES;  // DMA instructions per wave per tile
     const int i = lane & 31, h = lane >> 5;
     const int frag_base = (i >> 3) * 256 + 4 * ((2 * h + ((i >> 2) & 1)) ^ (2 * ((i >> 3) & 1))) + (i & 3);
@@ -276,15 +277,19 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
 #pragma unroll
     for (int a = 0; a < NA; ++a) bsum[a] = 0.0f;
 
-    auto issue = [&](int64_t t, int buf) {
-        const char *as = a_src + t * A_BYTES;
+    // piece j (0 .. PER_WAVE-1) of tile t into stage `buf`: A pieces first, then X pieces
+    auto issue_piece = [&](int64_t t, int buf, int j) {
         const unsigned ad = lds_base + buf * STAGE_BYTES;
+        if (j < A_PIECES) {
+            lds_dma_16s(a_src + t * A_BYTES + (wave + 4 * j) * 1024, lane_off, ad + (wave + 4 * j) * 1024);
+        } else {
+            const int jx = j - A_PIECES;
+            lds_dma_16s(x_src + t * X_BYTES + (wave + 4 * jx) * 1024, lane_off, ad + A_BYTES + (wave + 4 * jx) * 1024);
+        }
+    };
+    auto issue = [&](int64_t t, int buf) {
 #pragma unroll
-        for (int j = 0; j < A_PIECES; ++j) lds_dma_16s(as + (wave + 4 * j) * 1024, lane_off, ad + (wave + 4 * j) * 1024);
-        const char *xs = x_src + t * X_BYTES;
-        const unsigned xd = ad + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < X_PIECES; ++j) lds_dma_16s(xs + (wave + 4 * j) * 1024, lane_off, xd + (wave + 4 * j) * 1024);
+        for (int j = 0; j < PER_WAVE; ++j) issue_piece(t, buf, j);
     };
 
     // prologue: NSTAGE-1 tiles in flight (tiles past the end are re-reads of the last tile: the
@@ -295,12 +300,12 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
         wait_vmcnt<(NSTAGE - 2) * PER_WAVE>();   // tile t landed (this wave's pieces) ...
         __builtin_amdgcn_s_barrier();            // ... and everybody else's; stage (t-1) is free again
         asm volatile("" ::: "memory");
-        {
-            const int64_t tn = t + NSTAGE - 1;
-            int nb = buf + NSTAGE - 1;
-            if (nb >= NSTAGE) nb -= NSTAGE;
-            issue(tn < t1 ? tn : t1 - 1, nb);
-        }
+        // the tile NSTAGE-1 ahead goes into the stage everybody just left: its DMA pieces are issued one per
+        // k-step below, between the MFMAs, instead of as a 1 k-cycle burst in front of them
+        const int64_t tn_raw = t + NSTAGE - 1;
+        const int64_t tn = tn_raw < t1 ? tn_raw : t1 - 1;
+        int nbuf = buf + NSTAGE - 1;
+        if (nbuf >= NSTAGE) nbuf -= NSTAGE;
         // Fragments out of the TF-layout tiles (mlp_layout.h): lane (i, h) of k-step s wants sample 2s + h,
         // feature 32 FB + i, which sits at float FB*1024 + (i>>3)*256 + 16*(s ^ (i>>4)) + 4*((2h + ((i>>2)&1)) ^ (2*((i>>3)&1)))
         // + (i&3) of its tile: one per-lane base for even and one for odd s, plus compile-time offsets.
@@ -327,6 +332,7 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
         for (int s = 0; s < 16; ++s) {
             lds_fragments_ready();   // k-step s has landed
             if (s + 1 < 16) DW_FETCH(s + 1)
+            if (s < PER_WAVE) issue_piece(tn, nbuf, s);
 #pragma unroll
             for (int nb = 0; nb < NA; ++nb) {
                 bsum[nb] += a[s & 1][nb];
