@@ -250,15 +250,19 @@ template <int NFB>
 __device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, int h, const f32x16 *blk) {
     const int i = (int)(m & 31);
     const uint64_t tile_addr = reinterpret_cast<uint64_t>(plane + (m - i) * width);
-    char *tile = reinterpret_cast<char *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(tile_addr >> 32)) << 32) |
-                                          (unsigned)__builtin_amdgcn_readfirstlane((int)tile_addr));
+    // (address space 1 = global: rebuilt from integers the pointer would otherwise be generic, and a flat store
+    // also counts in lgkmcnt, i.e. the LDS fragment waits of the following MFMA pair would wait for it)
+    typedef __attribute__((address_space(1))) char global_char;
+    global_char *tile = reinterpret_cast<global_char *>(
+        ((uint64_t)__builtin_amdgcn_readfirstlane((int)(tile_addr >> 32)) << 32) |
+        (unsigned)__builtin_amdgcn_readfirstlane((int)tile_addr));
     const unsigned unit = (unsigned)(2 * i + h);
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
-            *reinterpret_cast<f32x4 *>(tile + (4 * fb + q) * 1024 + ((unit ^ (2u * q)) << 4)) = v;
+            *reinterpret_cast<__attribute__((address_space(1))) f32x4 *>(tile + (4 * fb + q) * 1024 + ((unit ^ (2u * q)) << 4)) = v;
         }
 }
 
