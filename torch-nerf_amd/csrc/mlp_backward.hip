@@ -105,9 +105,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         // MFMAs to drain before the next acquire's vmcnt(0) would wait for them.
 
         // ---- dY9 = (W_out^T d y10) . [h9 > 0]   (vector ALU, 3 x 128 MACs per sample)
+        // ReLU masks are fetched one stage ahead of their use: a 16-byte global load issued inside the seam that
+        // needs it costs its whole latency there (no MFMA is in flight to cover it)
+        u32x4 mk = masks[(int64_t)8 * MP * 2 + 2 * m + h];
         const char *w = lds + pipe.acquire();
         {
-            const u32x4 mk = masks[(int64_t)8 * MP * 2 + 2 * m + h];
 #pragma unroll
             for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
                 }
         }
         save_plane<4>(dy + dy9_plane(MP), 128, m, h, act);
+        mk = masks[(int64_t)7 * MP * 2 + 2 * m + h];   // for the seam of l = 7
 
         // ---- d y8[1:257] = W9[:, 0:256]^T dY9   (fc_9 input is cat([x[:,1:], dir]): nerf.py:116)
 #pragma unroll
@@ -146,11 +149,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
                 for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];  // fc_8 has no ReLU
                 if (h == 0) dy[dsig_plane(MP) + m] = dsig;
             } else {
-                const u32x4 mk = masks[(int64_t)l * MP * 2 + 2 * m + h];
 #pragma unroll
                 for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) act[fb][r] = masked(mk, fb, r, acc[fb][r]);
+                mk = masks[(int64_t)(l - 1) * MP * 2 + 2 * m + h];   // h(l-1): next seam (l = 1: the dY0 epilogue)
             }
             save_plane<8>(dy + dy_plane(MP, l), 256, m, h, act);
             if (l == 8) {  // the density row of fc_8 contributes w8[0, k] * d y8[0]
@@ -180,7 +183,6 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         TS();
         // ---- dY0: mask with h0 and store (no further propagation: the encodings carry no gradient)
         {
-            const u32x4 mk = masks[2 * m + h];
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
