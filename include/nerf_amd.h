@@ -147,6 +147,12 @@ int nerf_render_rays(const void *packed, const float *ray_o, const float *ray_d,
                      const float *u1, const float *u2, const float *u3, float *rgb,
                      float *weights_out, void *workspace, nerf_stream_t stream);
 
+/* ---- e: draws for ray-sharded rendering / training.  The reference draws with torch.rand / rand_like inside
+ * the sampler (R/renderer/ray_samplers/stratified_sampler.py:77,:109; R/renderer/ray_samplers/utils.py:43,:56);
+ * a sharded job needs draws that do not depend on the number of GPUs: out[i] = u(key, first + i), the
+ * splitmix64-finaliser stream of torch_nerf.amd.synth.counter_uniform (24-bit mantissa, [0,1)), bit for bit. */
+int nerf_counter_uniform(uint64_t key, int64_t first, int64_t count, float *out, nerf_stream_t stream);
+
 /* ---- f1: one torch.optim.Adam step as the reference configures it -- Adam(params, lr, eps) with
  * default betas, no weight decay, no amsgrad (R/../runners/runner_utils.py:691-695), stepped once per
  * batch (R/../runners/train.py:216) -- over ONE flat blob (both networks).  `step` counts from 1;

@@ -86,3 +86,22 @@ def test_sampling_ragged_shapes_vs_oracle(oracle, shape):
         assert np.array_equal(idx.cpu().numpy(), io)
         assert np.array_equal(pts.cpu().numpy(), po) and np.array_equal(delta.cpu().numpy(), dlo)
         assert np.array_equal(wt.cpu().numpy(), wo)
+
+
+def test_counter_uniform_kernel_is_the_numpy_stream_bit_for_bit():
+    """csrc/draws.hip against torch_nerf.amd.synth.counter_uniform (numpy) and against its own slices:
+    the draws of a ray range must not depend on which GPU asks for them."""
+    import numpy as np
+    import torch
+    from torch_nerf.amd import shard, synth
+    for seed, stream in ((0, 0), (123, 2), (2 ** 40 + 7, 3)):
+        ref = synth.counter_uniform(seed, stream, 70001)
+        full = shard.counter_uniform(seed, stream, 0, 70001, "cuda").cpu().numpy()
+        assert np.array_equal(full, ref)
+        part = shard.counter_uniform(seed, stream, 31337, 1025, "cuda").cpu().numpy()
+        assert np.array_equal(part, ref[31337:31337 + 1025])
+    assert shard.counter_uniform(1, 1, 5, 0, "cuda").numel() == 0
+    a = shard.ray_draws(9, 40, 20, 64, 128, "cuda")
+    b = shard.ray_draws(9, 0, 100, 64, 128, "cpu")
+    for x, y in zip(a, b):
+        assert torch.equal(x.cpu(), y[40:60])

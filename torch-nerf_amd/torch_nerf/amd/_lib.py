@@ -45,6 +45,7 @@ SIGNATURES = {
     "nerf_render_workspace_bytes": (_c_i64, [_c_i64, _c_int]),
     "nerf_render_rays": (_c_int, [_p, _p, _p, _c_i64, _c_int, _c_int, _p, _c_f, _p, _p, _p, _p, _p, _p,
                                   _p, _p]),
+    "nerf_counter_uniform": (_c_int, [ctypes.c_uint64, _c_i64, _c_i64, _p, _p]),
     "nerf_adam_step": (_c_int, [_p, _p, _p, _p, _c_i64, _c_i64, _c_d, _c_d, _c_d, _c_d, _c_d, _p]),
 }
 

@@ -282,6 +282,19 @@ class NerfMLPFunction(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
+# --------------------------------------------------------------------------- draws for sharded jobs (row e)
+def counter_uniform(key: int, first: int, count: int, device) -> torch.Tensor:
+    """`count` fp32 uniforms u(key, first + i) on the GPU (csrc/draws.hip); key is the 64-bit stream key."""
+    lib = _lib.load()
+    out = torch.empty((count,), dtype=torch.float32, device=device)
+    if not out.is_cuda:
+        raise RuntimeError("counter_uniform: the HIP path needs a GPU device")
+    with torch.cuda.device(out.device):
+        _lib.check(lib.nerf_counter_uniform(key & 0xFFFFFFFFFFFFFFFF, int(first), int(count), _ptr(out), _stream()),
+                   "nerf_counter_uniform")
+    return out
+
+
 # --------------------------------------------------------------------------- optimizer (row f1)
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
               step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
