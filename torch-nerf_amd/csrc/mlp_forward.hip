@@ -77,7 +77,15 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
     };
     load_raw(blockIdx.x);
 
+#ifdef X_TIMELINE   // scripts/timeline.py: cycle stamps of workgroup 0, written behind the 3 M colours
+    unsigned long long *tl = reinterpret_cast<unsigned long long *>(rgb_out + 3 * M);
+    int tl_n = 0;
+#define TS() do { if (blockIdx.x == 0 && tid == 0) tl[tl_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TS() do {} while (0)
+#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        TS();
         const int64_t m = tile * TILE_SAMPLES + wave * 32 + i;
         const bool valid = m < M;
         const int64_t mc = valid ? m : M - 1;
@@ -117,6 +125,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
         f32x16 acc[8], act[8];
 
         // ---- fc_in (nerf.py:102): one pair = the two 32-wide halves of the encoded position
+        TS();
         {
             const char *w = lds + pipe.acquire();
             if (SAVE) {
@@ -132,7 +141,9 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
         // pair, so its vector-ALU work and stores overlap the DMA wait and the first MFMAs.
         float sigma_pre = 0.0f;
         for (int l = 1; l <= 8; ++l) {
+            TS();
             const char *w = lds + pipe.acquire();
+            TS();
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
@@ -143,11 +154,13 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
             }
             if (l == 8) sigma_pre = half_dot<8>(cb + CB_W8ROW0, act, h);  // density row of fc_8
             load_bias<8>(acc, l < 8 ? cb + CB_BIAS + l * 256 : cb + CB_BIAS8, h);
+            TS();
             if (l == 5) {
                 mma_pair<8>(acc, pe[0], pe[1], w, offq, pipe);
                 w = lds + pipe.acquire();
             }
             mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
+            TS();
 #pragma unroll
             for (int pr = 1; pr < 4; ++pr) {
                 w = lds + pipe.acquire();
@@ -156,6 +169,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
         }
 
         // ---- fc_9 on cat([x[:,1:], view_dir]) -- features FIRST (:116-118); fc_8 has no ReLU (:113)
+        TS();
         {
             const char *w = lds + pipe.acquire();
 #pragma unroll
@@ -172,6 +186,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
             mma_chunk<4, 0, 16>(acc, de, w, offq, &pipe);
             pipe.issue_done();
         }
+        TS();
         sigma_pre += __shfl_xor(sigma_pre, 32, WAVE);
         const float sigma = fmaxf(sigma_pre + cb[CB_SCALARS], 0.0f);  // relu(x[:,0]) (:115)
 #pragma unroll
