@@ -101,6 +101,10 @@ int nerf_mlp_pack(const float *params, void *packed, nerf_stream_t stream);
  * sigma (M,), rgb (M,3).  `saved` = NULL for inference, or nerf_mlp_saved_bytes(M)
  * bytes that receive the activation record nerf_mlp_backward needs. */
 int64_t nerf_mlp_saved_bytes(int64_t M);
+/* Float offset of element (sample m, feature k) inside a plane of `width` (256 | 128 | 64 | 32) features per
+ * sample of the activation record / gradient workspace ("TF" layout, csrc/mlp_layout.h): host-side, for
+ * tools and tests; the record's planes are otherwise opaque. */
+int64_t nerf_mlp_plane_offset(int width, int64_t m, int k);
 int nerf_mlp_forward(const void *packed, const float *pos, const float *view_dir, int64_t M,
                      int encoded, float *sigma, float *rgb, void *saved, nerf_stream_t stream);
 

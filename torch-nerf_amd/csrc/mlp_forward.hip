@@ -250,6 +250,11 @@ int launch_forward(const void *packed, const float *pos, const float *dir, int64
 
 }  // namespace
 
+NERF_API int64_t nerf_mlp_plane_offset(int width, int64_t m, int k) {
+    if ((width != 256 && width != 128 && width != 64 && width != 32) || m < 0 || k < 0 || k >= width) return -1;
+    return mlp::tf_offset(width, m, k);
+}
+
 NERF_API int64_t nerf_mlp_saved_bytes(int64_t M) {
     return M < 0 ? 0 : mlp::padded_rows(M) * (int64_t)mlp::SAVED_BYTES_PER_SAMPLE;
 }

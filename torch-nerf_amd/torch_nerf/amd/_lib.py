@@ -33,6 +33,7 @@ SIGNATURES = {
     "nerf_mlp_param_count": (_c_i64, []),
     "nerf_mlp_packed_bytes": (_c_i64, []),
     "nerf_mlp_pack": (_c_int, [_p, _p, _p]),
+    "nerf_mlp_plane_offset": (_c_i64, [_c_int, _c_i64, _c_int]),
     "nerf_mlp_saved_bytes": (_c_i64, [_c_i64]),
     "nerf_mlp_forward": (_c_int, [_p, _p, _p, _c_i64, _c_int, _p, _p, _p, _p]),
     "nerf_mlp_packed_bf16_bytes": (_c_i64, []),
