@@ -129,11 +129,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         mk = masks[(int64_t)7 * MP * 2 + 2 * m + h];   // for the seam of l = 7
 
         // ---- d y8[1:257] = W9[:, 0:256]^T dY9   (fc_9 input is cat([x[:,1:], dir]): nerf.py:116)
-#pragma unroll
-        for (int fb = 0; fb < 8; ++fb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
-        mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
+        mma_pair<8, true>(acc, act[0], act[1], w, offq, pipe);   // accumulators start from C = 0
         w = lds + pipe.acquire();
         mma_pair<8>(acc, act[2], act[3], w, offq, pipe);
 
@@ -165,14 +161,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[fb][4 * q + j] = wv[j] * dsig;
                     }
-            } else {
-#pragma unroll
-                for (int fb = 0; fb < 8; ++fb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
             }
             TS();
-            mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
+            if (l == 8) mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
+            else mma_pair<8, true>(acc, act[0], act[1], w, offq, pipe);   // accumulators start from C = 0
             TS();
 #pragma unroll
             for (int pr = 1; pr < 4; ++pr) {

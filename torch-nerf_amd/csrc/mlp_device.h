@@ -157,7 +157,7 @@ __device__ __forceinline__ void lds_fragments_ready() {
     __builtin_amdgcn_sched_barrier(0);  // ... and the consumers of the fragment stay below it
 }
 
-template <int NFB, int FIRST_PIECE = 0, int N_PIECES = 0>
+template <int NFB, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, const char *chunk,
                                           const int (&offq)[4], const Pipe *pipe = nullptr) {
     constexpr int GROUPS = 4 * NFB, EVERY = N_PIECES > 0 ? GROUPS / N_PIECES : 1;
@@ -176,7 +176,12 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, con
         lds_fragments_ready();  // abuf[g & 1] has landed
         if (g + 1 < GROUPS) abuf[(g + 1) & 1] = lds_read_fragment(addr[(g + 1) / NFB], ((g + 1) % NFB) * 4096);
         const f32x4 a = abuf[g & 1];
-        acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * q + 0], acc[fb], 0, 0, 0);
+        if (FRESH && q == 0) {   // the accumulator block starts here: C = 0 instead of 16 zeroing writes
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * q + 0], zero, 0, 0, 0);
+        } else {
+            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * q + 0], acc[fb], 0, 0, 0);
+        }
         acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * q + 1], acc[fb], 0, 0, 0);
         if (N_PIECES > 0 && g % EVERY == 0) pipe->issue_piece(FIRST_PIECE + g / EVERY);
         acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * q + 2], acc[fb], 0, 0, 0);
@@ -187,10 +192,10 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, con
 // One pipeline step: both chunks of the acquired pair.  The next pair's 16 DMA pieces are all
 // issued during the FIRST chunk, so the youngest of them still has a whole chunk of MFMAs
 // (8 k cycles) to land before the next acquire waits for it.
-template <int NFB>
+template <int NFB, bool FRESH = false>
 __device__ __forceinline__ void mma_pair(f32x16 (&acc)[8], const f32x16 &b0, const f32x16 &b1, const char *w,
                                          const int (&offq)[4], Pipe &pipe) {
-    mma_chunk<NFB, 0, 16>(acc, b0, w, offq, &pipe);
+    mma_chunk<NFB, 0, 16, FRESH>(acc, b0, w, offq, &pipe);
     mma_chunk<NFB>(acc, b1, w + CHUNK_BYTES, offq);
     pipe.issue_done();
 }
