@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Audit hand-issued LDS reads in the compiled kernels (guide section 5.7 item 1/4).
+"""Audit hand-issued LDS reads (and the ownership of M0) in the compiled kernels (guide section 5.7 item 1/4).
 
 For every inline-asm `ds_read_b128 v[a:b], ...` (between ;;#ASMSTART / ;;#ASMEND) check that no
 instruction READS or WRITES a register of v[a:b] before a later `s_waitcnt lgkmcnt(N)` that covers
@@ -36,10 +36,14 @@ def audit(path):
             continue
         op, _, rest = ln.partition(" ")
         toks = [t.strip().rstrip(",") for t in re.split(r"[ ,]+", rest) if t.strip()]
-        if op.startswith("ds_"):           # every LDS operation is a younger LGKM op for the pending reads
+        if not in_asm and re.search(r"\bm0\b", ln):
+            # the LDS-DMA pieces overwrite M0 without restoring it: nothing the compiler emits may depend on it
+            problems += 1
+            print(f"{path}:{no}: `{ln[:70]}` uses m0 outside the inline asm that owns it")
+        if op.startswith("ds_") and (op.startswith("ds_read_b128") or not in_asm or True):           # every LDS operation is a younger LGKM op for the pending reads
             for p in pending:
                 p[2] += 1
-            if in_asm and op == "ds_read_b128":
+            if in_asm and op in ("ds_read_b128", "ds_read_b32"):
                 pending.append([regs(toks[0]), no, 0])
                 total += 1
             continue
@@ -56,7 +60,7 @@ def audit(path):
             if touched & p[0]:
                 problems += 1
                 print(f"{path}:{no}: `{ln[:70]}` touches v{sorted(touched & p[0])} of the un-waited read at line {p[1]}")
-    print(f"{path}: {total} hand-issued ds_read_b128, {problems} problems")
+    print(f"{path}: {total} hand-issued LDS reads, {problems} problems")
     return problems
 
 
