@@ -182,6 +182,39 @@ def test_sharded_step_equals_full_batch_step():
     assert rel < 2e-5, rel
 
 
+def test_full_size_batch_gradient_is_additive_over_ray_chunks():
+    """BASELINE size (4096 rays x (64 + 192) samples, 800x800 camera): the gradient of the whole batch equals the
+    sum of the gradients of its four 1024-ray chunks -- a size-independent property of the whole
+    forward/backward chain (ray generation, both samplers, both MLPs, both integrals)."""
+    from torch_nerf.amd import train, shard, synth
+    from torch_nerf.src.renderer.ray_samplers import StratifiedSampler
+    size, n = 800, 4096
+    focal = float(synth.blender_focal(size))
+    cam = _camera(torch.from_numpy(synth.pose_spherical(37.0, -30.0, 4.0)), size, focal)
+    nets = _nets(7)
+    with torch.no_grad():
+        for net in nets:
+            net.fc_8.bias[0] += 0.5
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    pix = train.choose_pixels(size, size, n, gen)
+    gt = torch.rand((n, 3), device="cuda", generator=gen)
+    params = [p for net in nets for p in net.parameters()]
+
+    def grads_of(lo, hi):
+        for p in params:
+            p.grad = None
+        draws = shard.ray_draws(11, lo, hi - lo, 64, 128, "cuda")
+        c, f = train._render_pair(cam, nets[0], nets[1], pix[lo:hi], 64, 128, False, draws, StratifiedSampler())
+        ((torch.sum((c - gt[lo:hi]) ** 2) + torch.sum((f - gt[lo:hi]) ** 2)) / (3 * n)).backward()
+        return torch.cat([p.grad.reshape(-1) for p in params]).double()
+
+    full = grads_of(0, n)
+    parts = sum(grads_of(lo, lo + 1024) for lo in range(0, n, 1024))
+    rel = (torch.linalg.vector_norm(parts - full) / torch.linalg.vector_norm(full)).item()
+    assert torch.isfinite(full).all() and torch.linalg.vector_norm(full) > 0
+    assert rel < 1e-5, rel
+
+
 def test_choose_pixels_centre_crop_and_determinism():
     from torch_nerf.amd import train
     g1 = torch.Generator(device="cuda").manual_seed(11)
