@@ -355,9 +355,44 @@ def f8_adam():
          shapes=np.array([int(np.prod(s)) for s in shapes], dtype=np.int64))
 
 
+# ---------------------------------------------------------------- F9 checkpoint layout (row f3)
+def f9_checkpoint():
+    """The dictionary runners/runner_utils.py:737-775 (_save_ckpt) writes, built with the same statements on the
+    reference's own NeRF module (runner_utils itself needs hydra, which is absent here): only its STRUCTURE is
+    recorded -- key names, shapes, dtypes -- which is what a checkpoint-compatible build has to reproduce."""
+    enc = {"coord_enc": RefPE(3, 10, True), "dir_enc": RefPE(3, 4, True)}
+    default_scene = ref_scene.PrimitiveCube(ref_nerf.NeRF(63, 27), enc)
+    fine_scene = ref_scene.PrimitiveCube(ref_nerf.NeRF(63, 27), enc)
+    params = list(default_scene.radiance_field.parameters()) + list(fine_scene.radiance_field.parameters())
+    optimizer = torch.optim.Adam(params, lr=0.0005, eps=1e-8)
+    scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, pow(0.00005 / 0.0005, 1 / 300000))
+    for p in params:
+        p.grad = torch.ones_like(p)
+    optimizer.step()
+    scheduler.step()
+    ckpt = {"epoch": 7, "optimizer_state_dict": optimizer.state_dict()}
+    ckpt["scheduler_state_dict"] = scheduler.state_dict()
+    ckpt["scene_default"] = default_scene.radiance_field.state_dict()
+    ckpt["scene_fine"] = fine_scene.radiance_field.state_dict()
+    sd = ckpt["scene_default"]
+    opt = ckpt["optimizer_state_dict"]
+    save("f9_checkpoint",
+         top_keys=np.array(sorted(ckpt.keys())),
+         scene_keys=np.array(list(sd.keys())),
+         scene_shapes=np.array([list(v.shape) + [0] * (2 - v.ndim) for v in sd.values()], dtype=np.int64),
+         scene_dtypes=np.array([str(v.dtype) for v in sd.values()]),
+         optimizer_keys=np.array(sorted(opt.keys())),
+         param_group_keys=np.array(sorted(opt["param_groups"][0].keys())),
+         param_group_size=np.array([len(opt["param_groups"][0]["params"])]),
+         state_keys=np.array(sorted(opt["state"][0].keys())),
+         state_step=np.array([float(opt["state"][0]["step"])]),
+         scheduler_keys=np.array(sorted(ckpt["scheduler_state_dict"].keys())),
+         file_name=np.array(["ckpt_" + str(7).zfill(6) + ".pth"]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    every = dict(f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
+    every = dict(f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
                  f8=f8_adam)
     for name in (sys.argv[1:] or list(every)):      # e.g. `make_golden.py f8` rewrites one fixture
         every[name]()

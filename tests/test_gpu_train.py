@@ -140,6 +140,37 @@ def test_fused_adam_tracks_torch_adam_and_shares_the_blob():
         torch.testing.assert_close(p, q, rtol=0, atol=5e-8)
 
 
+def test_checkpoint_round_trip_between_fused_and_torch_adam(tmp_path):
+    """A checkpoint written while training with FusedAdam (reference layout, runner_utils.py:737-775) resumes
+    under torch.optim.Adam and keeps stepping identically to the fused optimizer."""
+    from torch_nerf.amd import checkpoint
+    from torch_nerf.amd.optim import FusedAdam
+    from torch_nerf.src.scene import PrimitiveCube
+    from torch_nerf.src.signal_encoder import PositionalEncoder
+    enc = {"coord_enc": PositionalEncoder(3, 10, True), "dir_enc": PositionalEncoder(3, 4, True)}
+    nets = _nets(11)
+    scenes = [PrimitiveCube(n, enc) for n in nets]
+    params = [p for n in nets for p in n.parameters()]
+    opt = FusedAdam(params, lr=5e-4)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, 0.99)
+    for s in range(2):
+        _fake_backward(nets, 50 + s)
+        opt.step(); sched.step()
+    checkpoint.save_checkpoint(tmp_path, 2, scenes[0], scenes[1], opt, sched)
+    other = _nets(12)
+    oscenes = [PrimitiveCube(n, enc) for n in other]
+    oparams = [p for n in other for p in n.parameters()]
+    topt = torch.optim.Adam(oparams, lr=1.0)
+    tsched = torch.optim.lr_scheduler.ExponentialLR(topt, 0.5)
+    assert checkpoint.load_checkpoint(tmp_path, oscenes[0], oscenes[1], topt, tsched) == 2
+    for p, q in zip(params, oparams):
+        assert q.is_cuda and torch.equal(p, q)
+    _fake_backward(nets, 60); _fake_backward(other, 60)
+    opt.step(); topt.step()
+    for p, q in zip(params, oparams):
+        torch.testing.assert_close(p, q, rtol=0, atol=5e-8)
+
+
 def _views(size=48, n_views=6):
     from torch_nerf.amd import procedural
     return procedural.make_views(n_views, size, size, torch.device("cuda"))

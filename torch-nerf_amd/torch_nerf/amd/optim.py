@@ -98,7 +98,12 @@ class FusedAdam(torch.optim.Optimizer):
                  data_parallel: Optional[bool] = None, process_group: Optional[dist.ProcessGroup] = None):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError(f"Invalid Adam hyper-parameters: lr={lr}, betas={betas}, eps={eps}")
-        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        # torch.optim.Adam's remaining group keys ride along at their defaults, so that a checkpoint written by one
+        # optimizer loads into the other (runner_utils.py:758-775 saves optimizer.state_dict()); settings the
+        # kernel does not implement are refused at step time
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False,
+                                      maximize=False, foreach=None, capturable=False, differentiable=False,
+                                      fused=None, decoupled_weight_decay=False))
         self._data_parallel = data_parallel
         self._process_group = process_group
         self._arenas = {}
@@ -145,6 +150,9 @@ class FusedAdam(torch.optim.Optimizer):
         for index, group in enumerate(self.param_groups):
             if not group["params"]:
                 continue
+            if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
+                raise NotImplementedError("FusedAdam implements Adam as the reference configures it: "
+                                          "no weight decay, no amsgrad, no maximize")
             arena = self._arena(index, group)
             runs = arena.gradient_runs()
             if all(g is None for *_, g in runs):
