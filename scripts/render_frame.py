@@ -1,7 +1,7 @@
 """Render one full 800x800 frame (BASELINE configs[4] on however many GPUs are visible to the launcher)
 with shard.render_frame and report the frame time; optionally write a PNG.
 
-    python scripts/render_frame.py [--bf16] [--png out.png]
+    python scripts/render_frame.py [--bf16] [--llff] [--png out.png]        # --llff: BASELINE configs[3], 1008x756 NDC
     python -m torch.distributed.run --nproc-per-node 8 scripts/render_frame.py
 """
 import argparse, os, sys, time
@@ -17,16 +17,22 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--png", default=None)
 ap.add_argument("--size", type=int, default=800)
+ap.add_argument("--llff", action="store_true", help="LLFF fern geometry: 1008x756, forward-facing pose, NDC rays, t in [0,1]")
 args = ap.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1"))
 local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
 torch.cuda.set_device(local)
 if world > 1:
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-H = W = args.size
-focal = float(synth.blender_focal(W))
-cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
-                                torch.from_numpy(synth.pose_spherical(37.0, -30.0, 4.0)), 2.0, 6.0)
+if args.llff:   # W=1008, H=756, f ~ 815, near-identity 3x4 pose, ndc=True with (t_n, t_f) = (0, 1)
+    H, W, focal, ndc = 756, 1008, 815.0, True
+    cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
+                                    torch.from_numpy(synth.llff_like_pose()), 0.0, 1.0)
+else:
+    H = W = args.size
+    focal, ndc = float(synth.blender_focal(W)), False
+    cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
+                                    torch.from_numpy(synth.pose_spherical(37.0, -30.0, 4.0)), 2.0, 6.0)
 nets = []
 for seed in (3, 4):
     flat = synth.nerf_flat_params(seed=seed, sigma_bias=1.0, sigma_gain=30.0)
@@ -39,14 +45,14 @@ for seed in (3, 4):
 
 def frame():
     if args.bf16:
-        return shard.render_frame(cam, nets[0], nets[1], 64, 128, False, seed=1, bf16=True)
-    return shard.render_frame(cam, nets[0], nets[1], 64, 128, False, seed=1)
+        return shard.render_frame(cam, nets[0], nets[1], 64, 128, ndc, seed=1, bf16=True)
+    return shard.render_frame(cam, nets[0], nets[1], 64, 128, ndc, seed=1)
 
 
 frame(); torch.cuda.synchronize()
 t0 = time.perf_counter(); img = frame(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 if int(os.environ.get("RANK", "0")) == 0:
-    print(f"{H}x{W} frame, 64+128 samples, {'bf16' if args.bf16 else 'fp32'}, {world} GPU(s): {dt*1e3:.1f} ms  "
+    print(f"{W}x{H} {'LLFF-NDC' if args.llff else 'Blender'} frame, 64+128 samples, {'bf16' if args.bf16 else 'fp32'}, {world} GPU(s): {dt*1e3:.1f} ms  "
           f"({H*W/dt/1e3:.1f} k rays/s)", flush=True)
     if args.png:
         image.save_png(args.png, img.view(H, W, 3))
