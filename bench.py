@@ -2,7 +2,9 @@
 """Headline benchmark: rays/s on 4096-ray x (64 coarse + 128 fine)-sample batches.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+    (N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks are used as given; started as a
+     plain `python bench.py --gpus N` the script launches its own N ranks as a CHILD torch.distributed.run
+     process before anything touches the GPU and leaves with the child's return code)
 
 Workload (BASELINE.json configs[1]): Blender-lego geometry, 800x800, focal 1111.1, t in [2,6],
 no NDC, fp32, synthetic pose / pixels / weights (there is no dataset on the GPU box).
@@ -15,11 +17,19 @@ The JSON line also carries
   roofline     : the dominant kernel (fused posenc+MLP, fine-pass launch) against the fp32 MFMA
                  peak, timed live with HIP events on the launch stream inside the timed region
   cpu_baseline : the eager-PyTorch CPU port of the reference path (oracle/torch_port.py) on the
-                 host cores, same batch, bounded sample
+                 host cores, same batch, bounded sample; cpu_baseline_1thread: the same with the
+                 reference's own default torch.set_num_threads(1) (runners/runner_utils.py:427)
+  frame        : BASELINE configs[4] -- one 800x800 frame, rays sharded over the ranks, the RCCL all-gather
+                 included (STRONG scaling: fixed 640 000 rays), image hash checked against the 1-rank image
+  hbm_stages   : the HBM-bound stages (sampling, integral fwd/bwd) at full size against 8 TB/s
+  ms_per_step_median : median of per-step HIP-event times (the headline value stays total rays / total time)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,6 +47,8 @@ H = W = 800
 NEAR, FAR = 2.0, 6.0
 MLP_FLOP_PER_SAMPLE = 2 * 593408
 FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
+BF16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA (no 2:1 sparsity)
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E spec peak
 
 
 def build_scene(device):
@@ -138,7 +150,10 @@ def train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank, steps, 
 
 def bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank, steps, warmup):
     """Secondary figure (BASELINE configs[2]): the same render step with bf16 weights / layer inputs on the
-    bf16 MFMA path, and its PSNR against the fp32 step on identical pixels and draws."""
+    bf16 MFMA path, its PSNR against the fp32 step on identical pixels and draws, and the roofline object of
+    its dominant kernel (HIP events around every launch in the timed region, as for the fp32 kernel)."""
+    from torch_nerf.amd import ops
+
     def run(s, seed):
         torch.manual_seed(seed)
         return render_step(renderer, scene_c, scene_f, pix[s], local_rank)[1]
@@ -152,26 +167,36 @@ def bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank, steps, warmup):
         for s in range(warmup):
             run(s, s)
         torch.cuda.synchronize()
+        ops.KERNEL_EVENTS = []
         t0 = time.perf_counter()
         for s in range(warmup, warmup + steps):
             render_step(renderer, scene_c, scene_f, pix[s % len(pix)], local_rank)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
         for net in nets:
             net.bf16_inference = False
+    durs = [(M, e0.elapsed_time(e1)) for tag, M, e0, e1 in events if tag == "mlp_forward_bf16"]
+    total_ms = sum(ms for _, ms in durs)
+    achieved = sum(M for M, _ in durs) * MLP_FLOP_PER_SAMPLE / (total_ms * 1e-3) / 1e12
+    fine = [ms for M, ms in durs if M == RAYS * (N_COARSE + N_FINE)]
+    roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": ops.DOMINANT_KERNEL_BF16 + ", 2 launches/step", "launches": len(durs),
+                "ms_per_launch": round(total_ms / len(durs), 4),
+                "fine_ms_per_launch": round(float(np.mean(fine)), 4) if fine else None}
     return {"rays_per_s": RAYS * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
             "psnr_vs_fp32_db": round(10.0 * np.log10(1.0 / mse), 2) if mse > 0 else None,
-            "max_abs_err_vs_fp32": (got - ref).abs().max().item(),
+            "max_abs_err_vs_fp32": (got - ref).abs().max().item(), "roofline": roofline,
             "what": "render step with bf16 weights + bf16 layer inputs (v_mfma_f32_32x32x16_bf16, fp32 accumulate)"}
 
 
 def cpu_baseline(flats, focal, pose, device):
-    """Eager-torch CPU port on the host cores; returns the JSON object + PSNR of HIP vs port."""
+    """Eager-torch CPU port on the host cores; returns the JSON objects (all cores, 1 thread) + PSNR of HIP vs port."""
     from oracle import torch_port as TP
     from torch_nerf.amd import ops, shard, synth
 
     cores = host_cores()
-    torch.set_num_threads(cores)
     params = [{k: torch.from_numpy(v.copy()) for k, v in synth.split_flat_params(f).items()} for f in flats]
 
     def run(n_rays):
@@ -182,6 +207,19 @@ def cpu_baseline(flats, focal, pose, device):
             out = TP.render_batch(params[0], params[1], pix, H, W, focal, pose, NEAR, FAR, N_COARSE, N_FINE, draws)
         return time.perf_counter() - t0, pix, draws, out
 
+    # ---- the reference's own default: torch.set_num_threads(1) (runners/runner_utils.py:427); ~8 s of CPU work
+    torch.set_num_threads(1)
+    run(32)
+    t_probe, *_ = run(64)
+    n1 = int(min(1024, max(64, 64 * (8.0 / max(t_probe, 1e-3))))) // 64 * 64
+    secs1, *_ = run(n1)
+    one = {"value": n1 / secs1, "unit": "rays/s", "cores": 1, "kind": "port",
+           "sample": f"{n1} of the 4096 rays of one batch, coarse 64 + fine 64+128, forward, eager PyTorch CPU port "
+                     f"(oracle/torch_port.py), torch.set_num_threads(1) as runners/runner_utils.py:427 sets it, "
+                     f"{secs1:.1f} s"}
+
+    # ---- all host cores the cgroup grants
+    torch.set_num_threads(cores)
     run(64)                                   # warm-up (thread pool, MKL)
     t_probe, *_ = run(256)
     n = int(min(RAYS, max(256, 256 * (12.0 / max(t_probe, 1e-3)))))   # aim at ~12 s of CPU work
@@ -208,7 +246,110 @@ def cpu_baseline(flats, focal, pose, device):
                       f"port of the reference path (oracle/torch_port.py), {cores} threads, {secs:.1f} s per pass"}
     quality = {"psnr_vs_cpu_port_db": (None if psnr == float("inf") else round(psnr, 2)),
                "max_abs_pixel_err_vs_cpu_port": err, "coarse_max_abs_err": (g_c.cpu() - c_rgb).abs().max().item()}
-    return base, quality
+    return base, one, quality
+
+
+def hbm_stages(device, reps=20):
+    """the stages outside the MLP are HBM-bound and reported separately against 8 TB/s.
+    Each kernel at the full batch (4096 rays; 64 or 64+128 samples), HIP events on the launch stream around
+    every launch, median; bytes = the algorithmic traffic of the stage."""
+    from torch_nerf.amd import ops
+    n, Sc, Sf = RAYS, N_COARSE, N_FINE
+    S = Sc + Sf
+    g = torch.Generator(device=device).manual_seed(5)
+    o = torch.randn((n, 3), device=device, generator=g)
+    d = torch.randn((n, 3), device=device, generator=g)
+    t_bins = torch.linspace(NEAR, FAR, Sc + 1, device=device)[:-1]
+    ps = (FAR - NEAR) / Sc
+    u1, u2, u3 = (torch.rand((n, k), device=device, generator=g) for k in (Sc, Sf, Sf))
+    w = torch.rand((n, Sc), device=device, generator=g)
+    sigma = torch.rand((n, S), device=device, generator=g) * 3
+    rad = torch.rand((n, S, 3), device=device, generator=g)
+    delta = torch.full((n, S), 4.0 / S, device=device)
+    g_rgb = torch.randn((n, 3), device=device, generator=g)
+    cases = {
+        "stratified": (lambda: ops.sample_stratified(o, d, t_bins, ps, u1), n * Sc * 32 + n * 24,
+                       "u1 4 B in; pts 12 + dirs 12 + delta 4 B out per sample; o, d per ray"),
+        "hierarchical": (lambda: ops.sample_hierarchical(o, d, t_bins, ps, w.clone(), u1, u2, u3),
+                         n * (Sc * 12 + Sf * 8 + S * 28 + 24),
+                         "weights 4 B read + 4 B written back, u1 4 B per coarse sample; u2, u3 4 B per fine sample; "
+                         "pts 12 + dirs 12 + delta 4 B out per sorted sample; o, d per ray"),
+        "composite_fwd": (lambda: ops.composite_forward(sigma, rad, delta), n * S * 24 + n * 12,
+                          "sigma 4 + radiance 12 + delta 4 B in, weights 4 B out per sample; rgb 12 B per ray"),
+        "composite_bwd": (lambda: ops.composite_backward(sigma, rad, delta, g_rgb), n * S * 36 + n * 12,
+                          "sigma 4 + radiance 12 + delta 4 B in, g_sigma 4 + g_radiance 12 B out per sample; "
+                          "g_rgb 12 B per ray"),
+    }
+    out = {}
+    for name, (fn, nbytes, what) in cases.items():
+        for _ in range(3):
+            fn()
+        ms = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            ms.append((e0, e1))
+        torch.cuda.synchronize()
+        t = float(np.median([a.elapsed_time(b) for a, b in ms]))     # includes the torch.empty of the outputs
+        gbs = nbytes / (t * 1e-3) / 1e9
+        out[name] = {"us": round(t * 1e3, 2), "bytes": nbytes, "achieved_GBs": round(gbs, 1),
+                     "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "traffic": what}
+    out["note"] = (f"{n} rays x {Sc} (stratified) / {Sc}+{Sf} (others) samples; a stage of 5-40 us is launch- and "
+                   "latency-bound at this batch size, so the fraction is a lower bound on the kernel's streaming rate")
+    return out
+
+
+def frame_leg(nets, cam, rank, world, device):
+    """BASELINE configs[4]: one 800x800 frame (640 000 rays, 64+128), pixel ranges sharded over the ranks, each rank
+    renders coarse+fine for its range and ONE all-gather assembles the image (shard.render_frame).  Strong scaling."""
+    from torch_nerf.amd import shard
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1)      # warm-up
+    fence()
+    t0 = time.perf_counter()
+    img = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    digest = hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()[:16]
+    out = {"ms": dt * 1e3, "rays_per_s": H * W / dt, "rays": H * W, "n_gpus": world, "scaling": "strong",
+           "image_sha256_16": digest,
+           "what": f"{W}x{H} frame, 64+128 samples, fp32, contiguous pixel ranges over {world} rank(s), "
+                   "all-gather of the (H*W/world, 3) slabs included"}
+    if world > 1:
+        # the same frame rendered by rank 0 alone must be the same bits (draws are a function of the global ray index)
+        same = torch.ones(1, device=device)
+        if rank == 0:
+            solo = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1, single_rank=True)
+            out["image_sha256_16_one_rank"] = hashlib.sha256(solo.cpu().numpy().tobytes()).hexdigest()[:16]
+            same.fill_(float(torch.equal(solo, img)))
+        dist.broadcast(same, 0)
+        out["equals_one_rank_image"] = bool(same.item())
+    return out
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process (never exec
+    from a process that may have initialised the GPU; this one has not) and hand back its return code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -222,23 +363,49 @@ def main():
                     "(gradient all-reduce inside the optimizer); off by default so that a failure on one rank can "
                     "never stall the headline line")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-MFMA render measurement")
+    ap.add_argument("--no-frame", action="store_true", help="skip the 800x800 sharded full-frame leg")
+    ap.add_argument("--no-stages", action="store_true", help="skip the HBM-bound stage measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous, collectives and the JSON line only, no "
+                    "rendering: exercises the self-launch and the N-rank plumbing on a box without GPUs (CPU tests)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))       # nothing in this process has touched the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher provides WORLD_SIZE={world}")
+
+    if args.launch_check:
+        seen = torch.ones(1)
+        if world > 1:
+            dist.init_process_group("gloo" if args.backend != "nccl" or not torch.cuda.is_available() else "nccl")
+            dist.all_reduce(seen)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "rays/sec at 4096 rays x (64+128) samples", "value": None, "unit": "rays/s",
+                              "n_gpus": world, "rccl_ranks_seen": int(seen.item()), "launch_check": True,
+                              "steps": args.steps, "warmup": args.warmup}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.backend)
+        seen = torch.ones(1, device=device)
+        dist.all_reduce(seen)                      # every rank really is on the communicator
+        ranks_seen = int(seen.item())
 
     from torch_nerf.amd import ops
     renderer, scene_c, scene_f, nets, flats, cam, focal, pose = build_scene(device)
@@ -261,6 +428,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    step_events = []
     with torch.no_grad():
         for s in range(args.warmup):
             step(s)
@@ -268,19 +436,25 @@ def main():
         ops.KERNEL_EVENTS = []
         t0 = time.perf_counter()
         for s in range(args.warmup, n_steps):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
             step(s)
+            step_events.append(e0)
+        e_end = torch.cuda.Event(enable_timing=True)
+        e_end.record()
         fence()
         elapsed = time.perf_counter() - t0
         events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    step_events.append(e_end)
+    per_step = [a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:])]
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    # ---- dominant kernel: fused posenc+MLP (mlp_forward_kernel), two launches per step:
-    # coarse pass M = 4096 x 64 and fine pass M = 4096 x 192.  achieved = algorithmic FLOPs of all its
-    # launches in the timed region / their summed HIP-event durations; ms_per_launch = their mean
-    # (what rocprofv3 --stats reports as the kernel's average).
+    # ---- dominant kernel: the fused MLP kernel, two launches per step: coarse pass M = 4096 x 64 and fine pass
+    # M = 4096 x 192.  achieved = algorithmic FLOPs of all its launches in the timed region / their summed
+    # HIP-event durations; ms_per_launch = their mean (what rocprofv3 --stats reports as the kernel's average).
     durs = [(M, e0.elapsed_time(e1)) for tag, M, e0, e1 in events if tag == "mlp_forward"]
     total_ms = sum(ms for _, ms in durs)
     total_flop = sum(M for M, _ in durs) * MLP_FLOP_PER_SAMPLE
@@ -293,7 +467,7 @@ def main():
         traffic = json.load(open(tpath)).get("mlp_forward_hbm_bytes_per_launch")
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "kernel": "mlp_forward_kernel<false,false> (fused posenc + 11-layer MLP), 2 launches/step",
+                "kernel": ops.DOMINANT_KERNEL + ", 2 launches/step",
                 "launches": len(durs), "ms_per_launch": round(total_ms / len(durs), 4),
                 "fine_ms_per_launch": round(fine_ms, 4), "coarse_ms_per_launch": round(coarse_ms, 4),
                 "flop_per_launch_avg": total_flop / len(durs)}
@@ -306,6 +480,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_median": float(np.median(per_step)),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -315,6 +490,8 @@ def main():
                                "forward render through VolumeRenderer.render_scene (coarse net + fine net)",
                    "rays_per_gpu_per_step": RAYS, "global_rays_per_step": world * RAYS,
                    "parallelism": f"ray-shard x{world}" + (" + all-gather" if world > 1 else "")},
+        "rccl_ranks_seen": ranks_seen,
+        "backend": args.backend if world > 1 else None,
         "roofline": roofline,
     }
     # secondary legs never take the headline line down with them
@@ -324,17 +501,22 @@ def main():
         except Exception as exc:  # noqa: BLE001
             return {"error": f"{type(exc).__name__}: {exc}"[:300], "leg": name}
 
+    if not args.no_frame:       # collective: every rank takes part
+        result["frame"] = guarded("frame", lambda: frame_leg(nets, cam, rank, world, device))
     if world == 1 and not args.no_bf16:
         result["bf16"] = guarded("bf16", lambda: bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank,
                                                           args.steps, 3))
     if (world == 1 and not args.no_train) or (world > 1 and args.train):
         result["train"] = guarded("train", lambda: train_leg(renderer, scene_c, scene_f, nets, pix, device,
                                                              local_rank, max(3, args.steps // 4), 2, world))
+    if rank == 0 and world == 1 and not args.no_stages:
+        result["hbm_stages"] = guarded("hbm_stages", lambda: hbm_stages(device))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out = guarded("cpu_baseline", lambda: cpu_baseline(flats, focal, pose, device))
         if isinstance(out, tuple):
-            base, quality = out
+            base, one, quality = out
             result["cpu_baseline"] = base
+            result["cpu_baseline_1thread"] = one
             result.update(quality)
             result["speedup_vs_cpu_baseline"] = result["value"] / base["value"]
         else:

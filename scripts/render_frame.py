@@ -2,6 +2,7 @@
 with shard.render_frame and report the frame time; optionally write a PNG.
 
     python scripts/render_frame.py [--bf16] [--llff] [--png out.png]        # --llff: BASELINE configs[3], 1008x756 NDC
+    python scripts/render_frame.py --llff --spiral 4 [--png out_%03d.png]   # 4 evenly spaced poses of the LLFF spiral path
     python -m torch.distributed.run --nproc-per-node 8 scripts/render_frame.py
 """
 import argparse, os, sys, time
@@ -18,6 +19,8 @@ ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--png", default=None)
 ap.add_argument("--size", type=int, default=800)
 ap.add_argument("--llff", action="store_true", help="LLFF fern geometry: 1008x756, forward-facing pose, NDC rays, t in [0,1]")
+ap.add_argument("--spiral", type=int, default=0, help="with --llff: render this many poses of the spiral render path "
+                "(synth.llff_spiral_poses = load_llff.py:519-559 on a synthetic forward-facing pose set)")
 args = ap.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1"))
 local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
@@ -50,6 +53,18 @@ def frame():
 
 
 frame(); torch.cuda.synchronize()
+if args.llff and args.spiral > 0:   # row f3: walk the render path the LLFF loader would hand to runners/render.py
+    import numpy as np
+    poses, bounds = synth.llff_like_pose_set(20, seed=0)
+    path = synth.llff_spiral_poses(synth.recenter_poses(poses), bounds)
+    for k in np.linspace(0, len(path), args.spiral, endpoint=False).astype(int):
+        cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
+                                        torch.from_numpy(path[k]), 0.0, 1.0)
+        t0 = time.perf_counter(); img = frame(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"spiral pose {k:3d}/{len(path)}: {dt*1e3:.1f} ms, mean colour {img.mean(0).tolist()}", flush=True)
+            if args.png:
+                image.save_png(args.png % k if "%" in args.png else args.png, img.view(H, W, 3))
 t0 = time.perf_counter(); img = frame(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 if int(os.environ.get("RANK", "0")) == 0:
     print(f"{W}x{H} {'LLFF-NDC' if args.llff else 'Blender'} frame, 64+128 samples, {'bf16' if args.bf16 else 'fp32'}, {world} GPU(s): {dt*1e3:.1f} ms  "

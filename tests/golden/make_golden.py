@@ -390,9 +390,49 @@ def f9_checkpoint():
          file_name=np.array(["ckpt_" + str(7).zfill(6) + ".pth"]))
 
 
+# ---------------------------------------------------------------- F10 LLFF render poses (row f3)
+def f10_llff_poses():
+    """utils/data/load_llff.py:213-376,519-559 on a synthetic forward-facing pose set.  The module imports
+    `imageio` (absent here) at its top for the image loader, which is out of scope: an empty stand-in module is
+    placed in sys.modules for the duration of THIS import only; none of the functions captured touches it."""
+    import types
+    stub = "imageio" not in sys.modules
+    if stub:
+        sys.modules["imageio"] = types.ModuleType("imageio")
+    try:
+        import torch_nerf.src.utils.data.load_llff as ref_llff
+    finally:
+        if stub:
+            del sys.modules["imageio"]
+    assert ref_llff.__file__.startswith(REFERENCE)
+    poses, z_bounds = synth.llff_like_pose_set(20, seed=0)
+    recentred = ref_llff.recenter_poses(poses)
+    avg = ref_llff.poses_avg(recentred)
+
+    def spiral(extr, bds, zflat):   # the statements of load_llff_data between poses_avg and the fp32 cast (:519-559)
+        c2w = ref_llff.poses_avg(extr)
+        up = ref_llff.normalize(extr[:, :, 1].sum(0))
+        close_depth, inf_depth = bds.min() * 0.9, bds.max() * 5.0
+        dt = 0.75
+        focal = 1.0 / (((1.0 - dt) / close_depth + dt / inf_depth))
+        rads = np.percentile(np.abs(extr[:, :, 3]), 90, 0)
+        n_key, n_rot = 120, 2
+        if zflat:
+            c2w[:3, 3] = c2w[:3, 3] + (-close_depth * 0.1) * c2w[:3, 2]
+            rads[2] = 0.0
+            n_rot, n_key = 1, 60
+        return np.array(ref_llff.render_path_spiral(c2w, up, rads, focal, z_rate=0.5, rots=n_rot,
+                                                    num_keyframe=n_key)).astype(np.float32)
+
+    save("f10_llff_poses", poses=poses, z_bounds=z_bounds, recentred=recentred, poses_avg=avg,
+         spiral=spiral(recentred, z_bounds, False), spiral_zflat=spiral(recentred, z_bounds, True),
+         extrinsic_probe=ref_llff.build_extrinsic(np.array([0.1, -0.2, 0.9]), np.array([0.05, 1.0, 0.0]),
+                                                  np.array([1.0, 2.0, 3.0])))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    every = dict(f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
+    every = dict(f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
                  f8=f8_adam)
     for name in (sys.argv[1:] or list(every)):      # e.g. `make_golden.py f8` rewrites one fixture
         every[name]()

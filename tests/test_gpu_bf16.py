@@ -1,6 +1,8 @@
 """BASELINE configs[2]: bf16 MLP weights (and layer inputs) on the bf16 MFMA path.  The 1e-5 bound is
-unreachable in bf16 by construction; the parity target is restated as a PSNR bound on pixel colours
-against the fp32 path: >= 40 dB, plus loose element-wise bounds on sigma / rgb."""
+unreachable in bf16 by construction; the parity target is restated as a PSNR bound: >= 40 dB
+against the REFERENCE's own outputs (golden F5 sigma / rgb, golden F7 pixels) and against the C oracle on a
+larger random batch, plus loose element-wise bounds.  The comparisons with the HIP fp32 kernel further down are
+secondary (they would move together with an fp32 regression)."""
 import numpy as np
 import pytest
 import torch
@@ -17,6 +19,62 @@ def dev(a):
 def psnr(a, b):
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)
+
+
+def npsnr(a, b):
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)
+
+
+@pytest.mark.parametrize("tag,kw", [("default", dict(seed=1)), ("dense", dict(seed=2, sigma_bias=1.0, sigma_gain=30.0))])
+def test_bf16_forward_against_golden_f5(golden, tag, kw):
+    """sigma / rgb of the reference's NeRF.forward (nerf.py:102-119) on 256 samples, both weight sets."""
+    g = golden("f5_mlp")
+    flat = dev(synth.nerf_flat_params(**kw))
+    s16, c16 = ops.mlp_forward_bf16(ops.mlp_pack_bf16(flat), dev(g["pts"]), dev(g["dirs"]))
+    s16, c16 = s16.cpu().numpy(), c16.cpu().numpy()
+    assert np.isfinite(s16).all() and np.isfinite(c16).all()
+    assert npsnr(c16, g[tag + "_rgb"]) > 40.0, npsnr(c16, g[tag + "_rgb"])
+    assert np.abs(c16 - g[tag + "_rgb"]).max() < 3e-2
+    ref = g[tag + "_sigma"]
+    assert np.all(np.abs(s16 - ref) <= 0.05 * np.abs(ref) + 0.05), np.abs(s16 - ref).max()
+
+
+def test_bf16_pixels_against_golden_f7(golden):
+    """Coarse + fine pass on the reference's own draws (volume_renderer.py:136-169 twice): pixel colours of the
+    bf16 path vs the reference's pixels; the fine pass is fed the reference's coarse weights as in the fp32 test."""
+    g = golden("f7_e2e")
+    H, W, focal, near, far = g["meta"]
+    H, W = int(H), int(W)
+    o, d = ops.generate_rays(H, W, (np.float32(focal), np.float32(focal), W / 2.0, H / 2.0),
+                             torch.from_numpy(g["pose"]), False, focal, near, "cuda", pix=dev(g["pix"]))
+    t_bins = torch.linspace(float(near), float(far), 65)[:-1].cuda()
+    ps = (float(far) - float(near)) / 64
+    pc = ops.mlp_pack_bf16(dev(synth.nerf_flat_params(seed=3, sigma_bias=1.0, sigma_gain=30.0)))
+    pf = ops.mlp_pack_bf16(dev(synth.nerf_flat_params(seed=4, sigma_bias=1.0, sigma_gain=30.0)))
+    c_rgb, c_w = ops.render_rays(pc, o, d, t_bins, ps, dev(g["u1c"]), bf16=True)
+    f_rgb, f_w = ops.render_rays(pf, o, d, t_bins, ps, dev(g["u1"]), weights=dev(g["coarse_w"]), u2=dev(g["u2"]),
+                                 u3=dev(g["u3"]), bf16=True)
+    for got, want in ((c_rgb, g["coarse_rgb"]), (f_rgb, g["fine_rgb"])):
+        got = got.cpu().numpy()
+        assert npsnr(got, want) > 40.0, npsnr(got, want)
+        assert np.abs(got - want).max() < 3e-2
+    # compositing weights: the quantity the fine pass samples from
+    assert np.abs(c_w.cpu().numpy() - g["coarse_w"]).max() < 3e-2
+    assert np.abs(f_w.cpu().numpy() - g["fine_w"]).max() < 5e-2
+
+
+def test_bf16_forward_against_oracle_random_batch(oracle):
+    """5000 random samples (ragged tile) against the C oracle's fp32 network."""
+    rng = np.random.RandomState(5)
+    M = 5000
+    pts = rng.uniform(-4, 4, (M, 3)).astype(np.float32)
+    dirs = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    flat = synth.nerf_flat_params(seed=4, sigma_bias=1.0, sigma_gain=30.0)
+    so, co = oracle.mlp_forward(flat, oracle.posenc(pts, 10), oracle.posenc(dirs, 4))
+    s16, c16 = ops.mlp_forward_bf16(ops.mlp_pack_bf16(dev(flat)), dev(pts), dev(dirs))
+    assert npsnr(c16.cpu().numpy(), co) > 40.0
+    assert np.all(np.abs(s16.cpu().numpy() - so) <= 0.05 * np.abs(so) + 0.05)
 
 
 @pytest.mark.parametrize("M", [1, 63, 256, 257, 5000, 70000])

@@ -105,3 +105,26 @@ def test_counter_uniform_kernel_is_the_numpy_stream_bit_for_bit():
     b = shard.ray_draws(9, 0, 100, 64, 128, "cpu")
     for x, y in zip(a, b):
         assert torch.equal(x.cpu(), y[40:60])
+
+
+@pytest.mark.parametrize("S", [64, 192, 300])
+def test_backward_transmittance_equals_forward_for_sharp_densities(oracle, S):
+    """The backward kernel rebuilds T_i per 64-sample step; its prefix must be the forward kernel's, bit for
+    bit, also when densities are sharp (sigma ~ 1e2..1e4) and the last sample carries tau = sigma * 1e8.
+    With g_rgb = (1, 0, 0), g_radiance[..., 0] IS the backward's weight w_i."""
+    rng = np.random.RandomState(S)
+    n = 256
+    sigma = (rng.gamma(0.5, 1.0, (n, S)) * 10.0 ** rng.uniform(0, 4, (n, 1))).astype(np.float32)
+    sigma[:, -1] = rng.uniform(50, 2e4, n).astype(np.float32)          # a dense far end: tau_last up to 2e12
+    c = rng.rand(n, S, 3).astype(np.float32)
+    t = np.sort(rng.uniform(2, 6, (n, S)).astype(np.float32), axis=1)
+    delta = np.diff(np.concatenate([t, np.full((n, 1), 1e8, np.float32)], 1), axis=1).astype(np.float32)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    _, w = ops.composite_forward(dev(sigma), dev(c), dev(delta))
+    g = np.zeros((n, 3), np.float32)
+    g[:, 0] = 1.0
+    gs, gc = ops.composite_backward(dev(sigma), dev(c), dev(delta), dev(g))
+    assert torch.equal(gc[..., 0], w), (gc[..., 0] - w).abs().max().item()
+    gso, _ = oracle.composite_backward(sigma, c, delta, g)
+    scale = np.abs(gso).max(axis=1, keepdims=True) + 1e-30
+    assert np.max(np.abs(gs.cpu().numpy() - gso) / scale) < 2e-5

@@ -324,6 +324,79 @@ def _two_steps(world):
     return torch.cat([p.detach().reshape(-1) for net in nets for p in net.parameters()])
 
 
+def test_fused_adam_keeps_step_counts_when_a_parameter_is_rehomed():
+    """Reassigning p.data (an EMA swap, a .to(), a manual re-initialisation) takes the parameter out of the
+    optimizer's blob; the arena is rebuilt on the next step and must carry the step counts over (they live as
+    host integers between checkpoints) -- otherwise Adam's bias correction restarts from step 1."""
+    from torch_nerf.amd.optim import FusedAdam
+    mine, ref = _nets(3), _nets(3)
+    for a, b in zip(mine, ref):
+        b.load_state_dict(a.state_dict())
+    params = [p for net in mine for p in net.parameters()]
+    ref_params = [p for net in ref for p in net.parameters()]
+    opt = FusedAdam(params, lr=5e-4, eps=1e-8)
+    ropt = torch.optim.Adam(ref_params, lr=5e-4, eps=1e-8)
+    for s in range(6):
+        _fake_backward(mine, 40 + s)
+        _fake_backward(ref, 40 + s)
+        if s == 3:      # mid-training: fresh storage for one tensor of each network, same values
+            for net in mine:
+                net.fc_2.weight.data = net.fc_2.weight.data.clone()
+            assert not opt._arenas[0].intact()
+        opt.step()
+        ropt.step()
+    assert opt._arenas[0].intact() and opt._arenas[0].steps == [6] * len(params)
+    assert float(opt.state_dict()["state"][0]["step"]) == 6.0
+    for (name, p), q in zip([(k, v) for net in mine for k, v in net.named_parameters()], ref_params):
+        torch.testing.assert_close(p, q, rtol=0, atol=8e-8, msg=name)
+
+
+def _uneven_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from torch_nerf.amd.optim import FusedAdam
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nets = _nets(5)
+        opt = FusedAdam([p for net in nets for p in net.parameters()], lr=5e-4)
+        if rank == 0:
+            _fake_backward(nets, 7)          # rank 1 back-propagated nothing this step (p.grad is None everywhere)
+        opt.step()
+        q.put((rank, torch.cat([p.detach().reshape(-1) for net in nets for p in net.parameters()]).cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_with_a_rank_without_gradients_does_not_hang():
+    """Every rank joins the gradient all-reduce, contributing zeros if it has no gradient: the step is the
+    average over ranks and the replicas stay identical (a rank that skipped the collective would hang the job)."""
+    import torch.multiprocessing as mp
+    from torch_nerf.amd.optim import FusedAdam
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0], got[1])
+    nets = _nets(5)
+    _fake_backward(nets, 7)
+    for net in nets:
+        for p in net.parameters():
+            p.grad = p.grad * 0.5           # mean of (g, 0)
+    opt = FusedAdam([p for net in nets for p in net.parameters()], lr=5e-4)
+    opt.step()
+    want = torch.cat([p.detach().reshape(-1) for net in nets for p in net.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got[0], want, rtol=0, atol=1e-7)
+
+
 def test_training_step_is_deterministic():
     """No atomics anywhere on the path: the same two steps twice give bit-identical parameters."""
     assert torch.equal(_two_steps(1), _two_steps(1))

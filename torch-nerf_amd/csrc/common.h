@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/nerf_amd.h"
 
 #define NERF_API extern "C" __attribute__((visibility("default")))
@@ -29,6 +31,13 @@ inline int check_launch(const char *what) {
 }
 
 inline hipStream_t as_stream(nerf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Per-DEVICE lazily created state (the only mutable state of the library): the CU count of the current device
+// and, per kernel, the set of device ordinals on which its dynamic-LDS limit has been raised
+// (hipFuncSetAttribute applies to the current device only).  Both are idempotent, so races are benign.
+int device_cus();
+typedef std::atomic<unsigned long long> DeviceMask;
+int ensure_dynamic_lds(const void *kernel, int bytes, DeviceMask &done, const char *what);
 
 }  // namespace nerf
 

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK *WAVE) void composite_fwd_kernel(
 // Reverse of the quadrature rule.  With G_i = g_rgb . c_i (+ g_w_i):
 //   dL/dc_i     = w_i g_rgb
 //   dL/dsigma_i = delta_i (T_{i+1} G_i - sum_{k>i} w_k G_k),   T_{i+1} = exp(-sum_{j<=i} tau_j)
-// Two passes over the ray: a forward prefix pass to get the total optical depth per
+// Two passes over the ray: a forward prefix pass to get the optical depth in front of every
 // 64-sample step, then steps are visited last-to-first with a suffix carry.
 __global__ __launch_bounds__(RAYS_PER_BLOCK *WAVE) void composite_bwd_kernel(
     const float *__restrict__ sigma, const float *__restrict__ radiance,
@@ -95,22 +95,33 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK *WAVE) void composite_bwd_kernel(
     const float *cl = radiance + ray * S * 3;
     const float g0 = g_rgb[3 * ray], g1 = g_rgb[3 * ray + 1], g2 = g_rgb[3 * ray + 2];
     const int nsteps = (S + WAVE - 1) / WAVE;
-    // total optical depth in front of every step (exclusive over steps)
-    double total = 0.0;
-    for (int s0 = 0; s0 < S; s0 += WAVE) {
-        const int s = s0 + lane;
+    // optical depth in front of every 64-sample step, accumulated FROM THE FRONT exactly like the forward
+    // kernel's carry, and parked in lane `st` of a register.  (Rebuilding it as total - later steps cancels
+    // catastrophically: the last sample has tau = sigma * 1e8, so the difference loses ~1e-6 .. 1e-4 absolute
+    // and forward and backward transmittances of the 192-sample fine pass disagree.)
+    double front = 0.0, before_of_lane = 0.0;
+    for (int st = 0; st < nsteps; ++st) {
+        const int s = st * WAVE + lane;
         const float tau = (s < S) ? sg[s] * dl[s] : 0.0f;
-        total += __shfl(wave_inclusive_scan((double)tau, lane), WAVE - 1, WAVE);
+        if (lane == (st & (WAVE - 1)) && st < WAVE) before_of_lane = front;
+        front += __shfl(wave_inclusive_scan((double)tau, lane), WAVE - 1, WAVE);
     }
     double suffix = 0.0;       // sum_{k in later steps} w_k G_k
-    double depth_after = total;  // optical depth up to the END of the current step
     for (int st = nsteps - 1; st >= 0; --st) {
         const int s = st * WAVE + lane;
         const bool live = s < S;
         const float tau = live ? sg[s] * dl[s] : 0.0f;
         const double incl = wave_inclusive_scan((double)tau, lane);
-        const double step_sum = __shfl(incl, WAVE - 1, WAVE);
-        const double before = depth_after - step_sum;  // optical depth in front of this step
+        double before;           // optical depth in front of this step
+        if (st < WAVE) {
+            before = __shfl(before_of_lane, st, WAVE);
+        } else {                 // S > 4096: walk again from the front (same additions, same order)
+            before = 0.0;
+            for (int e = 0; e < st; ++e) {
+                const int se = e * WAVE + lane;   // e < st <= nsteps - 1: always a full step
+                before += __shfl(wave_inclusive_scan((double)(sg[se] * dl[se]), lane), WAVE - 1, WAVE);
+            }
+        }
         double excl = __shfl_up(incl, 1, WAVE);
         if (lane == 0) excl = 0.0;
         const float T = expf(-(float)(before + excl));
@@ -131,7 +142,6 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK *WAVE) void composite_bwd_kernel(
             g_radiance[(ray * S + s) * 3 + 2] = w * g2;
         }
         suffix += __shfl(rev, 0, WAVE);
-        depth_after = before;
     }
 }
 

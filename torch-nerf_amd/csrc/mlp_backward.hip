@@ -561,18 +561,6 @@ Plan make_plan(int64_t M, int cus) {
     return p;
 }
 
-int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
 inline int64_t align256f(int64_t floats) { return (floats + 63) & ~(int64_t)63; }
 
 }  // namespace
@@ -600,16 +588,14 @@ NERF_API int nerf_mlp_backward(const void *packed, const float *params, const fl
     }
     NERF_REQUIRE(packed && sigma && rgb && saved && g_sigma && g_rgb && workspace,
                  "nerf_mlp_backward: null pointer");
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_dx_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, mlp::LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_dw_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES) != hipSuccess)
-            return nerf::check_launch("nerf_mlp_backward: LDS attribute");
-        configured = true;
-    }
-    const int cus = device_cus();
+    static nerf::DeviceMask configured_dx{0}, configured_dw{0};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_dx_kernel), mlp::LDS_BYTES,
+                                          configured_dx, "nerf_mlp_backward: LDS attribute (dX)"))
+        return rc;
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_dw_kernel), DW_LDS_BYTES,
+                                          configured_dw, "nerf_mlp_backward: LDS attribute (dW)"))
+        return rc;
+    const int cus = nerf::device_cus();
     const int64_t MP = mlp::padded_rows(M);
     float *dy = static_cast<float *>(workspace);
     float *partial = dy + align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE);

@@ -72,7 +72,12 @@ __device__ __forceinline__ float relu1(float x) {
 // one 1-KiB piece per instruction, wave-uniform base + per-lane byte offset:
 // LDS[m0 + lane*16] <- global[src + lane_off].  The address arithmetic of a piece is then scalar (the
 // per-lane form costs a 64-bit vector add per piece, in issue slots the MFMA stream cannot hide) and M0 is
-// simply overwritten: nothing else in these kernels uses it (gfx9+ LDS instructions do not need it).
+// simply overwritten.  It cannot be declared: M0 is a RESERVED register for hipcc, which answers an "m0" clobber
+// with "reserved registers on the clobber list may not be preserved" (once per inlined piece) and keeps its own
+// hoisted M0 initialisations regardless.  So the contract is enforced from outside: gfx9+ LDS instructions do
+// not need M0, these kernels use nothing else that reads it (no s_movrel, no v_readlane with M0, no GWS), and
+// tests/test_isa_audit.py fails the CPU test suite if the emitted ISA of any MLP kernel ever reads M0 outside
+// a piece.
 __device__ __forceinline__ void lds_dma_16s(const char *src, unsigned lane_off, unsigned lds_dst) {
     asm volatile(
         "s_mov_b32 m0, %2\n\t"

@@ -216,31 +216,16 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-int num_compute_units() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
 template <bool ENCODED, bool SAVE>
 int launch_forward(const void *packed, const float *pos, const float *dir, int64_t M, float *sigma,
                    float *rgb, void *saved, hipStream_t stream) {
     auto kern = mlp_forward_kernel<ENCODED, SAVE>;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return nerf::check_launch("nerf_mlp_forward: LDS attribute");
-        configured = true;
-    }
+    static nerf::DeviceMask configured{0};  // one per template instance
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, configured,
+                                          "nerf_mlp_forward: LDS attribute"))
+        return rc;
     const int64_t ntiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES;
-    const int cus = num_compute_units();
+    const int cus = nerf::device_cus();
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, stream,
                        reinterpret_cast<const char *>(packed), pos, dir, M, sigma, rgb,

@@ -330,17 +330,11 @@ NERF_API int nerf_mlp_forward_bf16(const void *packed_bf16, const float *pos, co
     NERF_REQUIRE(M >= 0, "nerf_mlp_forward_bf16: negative M");
     if (M == 0) return NERF_OK;
     NERF_REQUIRE(packed_bf16 && pos && view_dir && sigma && rgb, "nerf_mlp_forward_bf16: null pointer");
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_forward_bf16_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, mlp::B16_LDS_BYTES) != hipSuccess)
-            return nerf::check_launch("nerf_mlp_forward_bf16: LDS attribute");
-        configured = true;
-    }
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
+    static nerf::DeviceMask configured{0};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_forward_bf16_kernel), mlp::B16_LDS_BYTES,
+                                          configured, "nerf_mlp_forward_bf16: LDS attribute"))
+        return rc;
+    const int cus = nerf::device_cus();
     const int64_t ntiles = (M + TILE - 1) / TILE;
     hipLaunchKernelGGL(mlp_forward_bf16_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(256),
                        mlp::B16_LDS_BYTES, nerf::as_stream(stream), static_cast<const char *>(packed_bf16), pos,

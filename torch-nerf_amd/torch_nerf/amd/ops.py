@@ -162,6 +162,9 @@ def mlp_pack(flat_params: torch.Tensor) -> torch.Tensor:
 # When set to a list, every MLP launch appends (tag, M, start_event, end_event) recorded on the
 # launch stream: bench.py uses it to time the dominant kernel inside the timed region.
 KERNEL_EVENTS = None
+# what rocprofv3 calls the kernel behind the "mlp_forward" tag on the inference path (bench.py roofline object)
+DOMINANT_KERNEL = "mlp_forward_kernel<false,false> (fused posenc + 11-layer MLP)"
+DOMINANT_KERNEL_BF16 = "mlp_forward_bf16_kernel (fused posenc + 11-layer MLP on v_mfma_f32_32x32x16_bf16)"
 
 
 def _timed(tag, M):

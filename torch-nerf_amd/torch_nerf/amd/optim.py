@@ -69,7 +69,8 @@ class _Arena:
 
     def publish_steps(self, state) -> None:
         for p, t in zip(self.params, self.steps):
-            state[p]["step"].fill_(float(t))
+            if p in state and "step" in state[p]:
+                state[p]["step"].fill_(float(t))
 
     def gradient_runs(self):
         """[(first, last, a, b, tensor-or-None)]: maximal runs params[first:last] = blob[a:b] of consecutive
@@ -119,6 +120,10 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdam: parameters must be on the GPU (no CPU fallback)")
                 if p.dtype != torch.float32:
                     raise ValueError("FusedAdam: fp32 parameters only")
+            if arena is not None:
+                # the step counts live as host integers in the arena between checkpoints: hand them (and, through
+                # the state's views, the moments) to the replacement -- e.g. after an EMA swap reassigned p.data
+                arena.publish_steps(self.state)
             arena = self._arenas[index] = _Arena(group["params"], self.state)
         return arena
 
@@ -155,8 +160,8 @@ class FusedAdam(torch.optim.Optimizer):
                                           "no weight decay, no amsgrad, no maximize")
             arena = self._arena(index, group)
             runs = arena.gradient_runs()
-            if all(g is None for *_, g in runs):
-                continue
+            if world == 1 and all(g is None for *_, g in runs):
+                continue          # (with world > 1 a rank without gradients still joins the all-reduce, with zeros)
             b1, b2 = group["betas"]
             if world > 1:
                 # every rank contributes its shard's gradient; a parameter without one contributes zeros,

@@ -110,13 +110,16 @@ def allreduce_gradients(parameters, group: Optional[dist.ProcessGroup] = None, a
 @torch.no_grad()
 def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, project_to_ndc: bool, seed: int,
                  group: Optional[dist.ProcessGroup] = None, rays_per_launch: int = 65536,
-                 bf16: bool = False) -> torch.Tensor:
-    """Full frame (H*W, 3) on every rank; each rank renders only its pixel range on its own GPU."""
+                 bf16: bool = False, single_rank: bool = False) -> torch.Tensor:
+    """Full frame (H*W, 3) on every rank; each rank renders only its pixel range on its own GPU.
+    single_rank=True: the calling rank renders the whole frame alone, no collective (the 1-GPU image a sharded
+    image must equal bit for bit)."""
     from torch_nerf.amd import ops
     from torch_nerf.src.renderer.ray_samplers import StratifiedSampler
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    on = dist.is_available() and dist.is_initialized() and not single_rank
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
     device = torch.device("cuda", torch.cuda.current_device())
     total = camera.img_height * camera.img_width
     lo, hi = shard_range(total, rank, world)
@@ -135,4 +138,4 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
         rgb, _ = ops.render_rays(packed_f, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1, weights=w, u2=u2,
                                  u3=u3, bf16=bf16)
         out[first - lo: first - lo + n] = rgb
-    return gather_image(out, total, group)
+    return out if single_rank else gather_image(out, total, group)

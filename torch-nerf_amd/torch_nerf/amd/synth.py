@@ -116,6 +116,89 @@ def llff_like_pose():
     return np.concatenate([R, t], axis=1).astype(np.float32)
 
 
+# ---------------------------------------------------------------- LLFF render poses
+# Pure functions of (poses, depth bounds): what utils/data/load_llff.py computes between loading the images
+# and returning `render_poses`.  The image / COLMAP loading around them stays out of scope.
+def unit(vec):
+    """vec / |vec| (load_llff.py:213-226)."""
+    vec = np.asarray(vec)
+    return vec / np.linalg.norm(vec)
+
+
+def build_extrinsic(z_vec, up_vec, camera_position):
+    """(3,4) camera-to-world [x | y | z | position] from a viewing axis and an up vector (load_llff.py:229-258):
+    x = unit(up x z), y = unit(z x x)."""
+    z = unit(z_vec)
+    x = unit(np.cross(up_vec, z))
+    y = unit(np.cross(z, x))
+    return np.stack([x, y, z, np.asarray(camera_position)], axis=1)
+
+
+def poses_avg(poses):
+    """The "central" pose of a set of (N,3,4) poses: mean position, summed z axes, summed y axes as the up
+    vector (load_llff.py:281-307)."""
+    poses = np.asarray(poses)
+    return build_extrinsic(unit(poses[:, :3, 2].sum(axis=0)), poses[:, :3, 1].sum(axis=0),
+                           poses[:, :3, 3].mean(axis=0))
+
+
+def recenter_poses(poses):
+    """Express every pose in the frame of the central pose (load_llff.py:353-376)."""
+    poses = np.asarray(poses)
+    out = poses + 0
+    last_row = np.array([[0.0, 0.0, 0.0, 1.0]])
+    centre = np.concatenate([poses_avg(poses), last_row], axis=0)
+    full = np.concatenate([poses[:, :3, :4], np.broadcast_to(last_row, (poses.shape[0], 1, 4))], axis=1)
+    out[:, :3, :4] = (np.linalg.inv(centre) @ full)[:, :3, :4]
+    return out
+
+
+def render_path_spiral(camera_to_world, up_vec, radiuses, focal, z_rate, rots, num_keyframe):
+    """Spiral of (3,4) poses around `camera_to_world`, every one looking at the point `focal` in front of it
+    (load_llff.py:310-350).  Returns a list, like the reference."""
+    c2w = np.asarray(camera_to_world)[:3, :4]
+    radii = np.array(list(radiuses) + [1.0])
+    target = c2w @ np.array([0.0, 0.0, -focal, 1.0])
+    poses = []
+    for theta in np.linspace(0.0, 2.0 * np.pi * rots, num_keyframe + 1)[:-1]:
+        position = c2w @ (np.array([np.cos(theta), -np.sin(theta), -np.sin(theta * z_rate), 1.0]) * radii)
+        poses.append(build_extrinsic(unit(position - target), up_vec, position))
+    return poses
+
+
+def llff_spiral_poses(extrinsics, z_bounds, path_zflat=False):
+    """`render_poses` exactly as load_llff_data derives them from the (already rescaled / recentred) poses and
+    depth bounds (load_llff.py:519-559): focus depth from the bounds, radii = 90th percentile of |position|,
+    120 key frames over 2 rotations (60 over 1, z-radius 0, for path_zflat).  fp32 (N,3,4)."""
+    extrinsics, z_bounds = np.asarray(extrinsics), np.asarray(z_bounds)
+    centre = poses_avg(extrinsics)
+    up = unit(extrinsics[:, :, 1].sum(0))
+    close_depth, inf_depth = z_bounds.min() * 0.9, z_bounds.max() * 5.0
+    dt = 0.75
+    focal = 1.0 / ((1.0 - dt) / close_depth + dt / inf_depth)
+    radii = np.percentile(np.abs(extrinsics[:, :, 3]), 90, 0)
+    keyframes, rotations = 120, 2
+    if path_zflat:
+        centre[:3, 3] = centre[:3, 3] + (-close_depth * 0.1) * centre[:3, 2]
+        radii[2] = 0.0
+        keyframes, rotations = 60, 1
+    return np.array(render_path_spiral(centre, up, radii, focal, z_rate=0.5, rots=rotations,
+                                       num_keyframe=keyframes)).astype(np.float32)
+
+
+def llff_like_pose_set(num=20, seed=0):
+    """(poses (num,3,4) float64, z_bounds (num,2)): a forward-facing capture like an LLFF scene -- cameras on a
+    jittered grid in front of the scene, all looking roughly down -z -- from the build's counter generator."""
+    u = counter_uniform(seed, 77, num * 8).astype(np.float64).reshape(num, 8)
+    poses = []
+    for k in range(num):
+        position = np.array([(u[k, 0] - 0.5) * 2.0, (u[k, 1] - 0.5) * 1.2, (u[k, 2] - 0.5) * 0.3])
+        look = np.array([(u[k, 3] - 0.5) * 0.2, (u[k, 4] - 0.5) * 0.2, 1.0])      # camera z axis points backwards
+        poses.append(build_extrinsic(look, np.array([(u[k, 5] - 0.5) * 0.1, 1.0, 0.0]), position))
+    z_bounds = np.stack([1.2 + u[:, 6], 8.0 + 6.0 * u[:, 7]], axis=1)
+    return np.array(poses), z_bounds
+
+
 def pixel_batch(seed, height, width, num_pixels):
     """A seeded sample of distinct pixel indices (int64), stand-in for np.random.choice."""
     rng = np.random.RandomState(seed)
