@@ -125,6 +125,9 @@ def test_backward_transmittance_equals_forward_for_sharp_densities(oracle, S):
     g[:, 0] = 1.0
     gs, gc = ops.composite_backward(dev(sigma), dev(c), dev(delta), dev(g))
     assert torch.equal(gc[..., 0], w), (gc[..., 0] - w).abs().max().item()
+    # g_sigma against the oracle (all-double arithmetic).  Rays whose first samples are already opaque have
+    # gradients ~1e-18 that consist of cancellation noise in fp32 (the reference's fp32 autograd has the same);
+    # so the yardstick is the ray's largest gradient, floored at 1e-6 of the batch's largest
     gso, _ = oracle.composite_backward(sigma, c, delta, g)
-    scale = np.abs(gso).max(axis=1, keepdims=True) + 1e-30
-    assert np.max(np.abs(gs.cpu().numpy() - gso) / scale) < 2e-5
+    scale = np.maximum(np.abs(gso).max(axis=1, keepdims=True), 1e-6 * np.abs(gso).max())
+    assert np.max(np.abs(gs.cpu().numpy() - gso) / scale) < 1e-4      # fp32 T / w (as in the forward), double sums

@@ -78,11 +78,14 @@ __device__ __forceinline__ float relu1(float x) {
 // not need M0, these kernels use nothing else that reads it (no s_movrel, no v_readlane with M0, no GWS), and
 // tests/test_isa_audit.py fails the CPU test suite if the emitted ISA of any MLP kernel ever reads M0 outside
 // a piece.
+#ifndef X_DMA_POLICY
+#define X_DMA_POLICY ""      // A/B knob: cache-policy suffix of the weight-stream loads (" nt", " sc0", " sc1")
+#endif
 __device__ __forceinline__ void lds_dma_16s(const char *src, unsigned lane_off, unsigned lds_dst) {
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, %1"
+        "global_load_lds_dwordx4 %0, %1" X_DMA_POLICY
         :
         : "v"(lane_off), "s"(src), "s"(lds_dst)
         : "memory");

@@ -130,21 +130,22 @@ __host__ __device__ constexpr int64_t dsig_plane(int64_t MP) { return MP * (256 
 constexpr int DY_FLOATS_PER_SAMPLE = 256 * 9 + 128 + 1;
 
 // ---- bf16 inference stream (BASELINE configs[2]: bf16 weights on v_mfma_f32_32x32x16_bf16).
-// [const block (fp32, as above)][step 0]...[step 20]; a step = 4 chunks = 64 KiB, a chunk = the LDS
-// image of W[:, 32 k-values] in bf16: 256 rows x 64 B.  Row n holds four 16-byte A fragments
-// (8 bf16 each), one per (k-step s, lane half h): element e is W[n][32 kb + 16 s + 8 (e>>2) + 4 h + (e&3)],
-// i.e. exactly the features the D fragment of the previous layer holds in registers 8s..8s+7 of
-// lane half h.  Fragment (s,h) of row n sits at slot (2s+h) ^ ((n>>2)&3): conflict-free ds_read_b128.
-//   step 0        fc_in            (chunks 0,1; 2,3 zero)      steps 12..15  fc_6, fc_7
-//   steps 1..8    fc_1 .. fc_4     (2 steps per layer)         steps 16,17   fc_8 rows 1..256
-//   step 9        fc_5[:, 0:63]    (chunks 0,1; 2,3 zero)      steps 18,19   fc_9[:, 0:256] (rows 0..127)
-//   steps 10,11   fc_5[:, 63:319]                              step 20       fc_9[:, 256:283] (chunk 0)
+// [const block (fp32, as above)][sub-step 0]...[sub-step 36]; a sub-step = 32 KiB = what one pipeline step of
+// mlp_forward_bf16.hip moves into one LDS ring slot.  A full chunk = the LDS image of W[:, 32 k-values] in bf16:
+// 256 rows x 64 B.  Row n holds four 16-byte A fragments (8 bf16 each), one per (k-step s, lane half h): element e
+// is W[n][32 kb + 16 s + 8 (e>>2) + 4 h + (e&3)], i.e. exactly the features the D fragment of the previous layer
+// holds in registers 8s..8s+7 of lane half h.  Fragment (s,h) of row n sits at slot (2s+h) ^ ((n>>2)&3):
+// conflict-free ds_read_b128.  A sub-step of a 256-row layer is two chunks (k-blocks 2j, 2j+1).  fc_9 has 128
+// rows: its chunks are 128 rows x 64 B = 8 KiB (same row format) and three of them share a sub-step.
+//   sub 0         fc_in   (encoded position, 63 -> 64)          subs 22..29   fc_6, fc_7
+//   subs 1..16    fc_1 .. fc_4  (4 per layer)                   subs 30..33   fc_8 rows 1..256
+//   sub 17        fc_5[:, 0:63]   (skip connection, pos first)  subs 34,35    fc_9[:, 0:96], fc_9[:, 96:192]
+//   subs 18..21   fc_5[:, 63:319]                               sub 36        fc_9[:, 192:256], fc_9[:, 256:283] (dir)
 constexpr int B16_CHUNK_BYTES = CHUNK_ROWS * CHUNK_K * 2;   // 16 KiB
-constexpr int B16_STEP_CHUNKS = 4;
-constexpr int B16_STEP_BYTES = B16_STEP_CHUNKS * B16_CHUNK_BYTES;  // 64 KiB
-constexpr int B16_STEPS = 21;
-constexpr int64_t B16_PACKED_BYTES = (int64_t)CONST_BYTES + (int64_t)B16_STEPS * B16_STEP_BYTES;
-constexpr int B16_LDS_BYTES = 2 * B16_STEP_BYTES + CONST_BYTES;  // two steps in the ring
+constexpr int B16_HALF_CHUNK_BYTES = B16_CHUNK_BYTES / 2;   // 8 KiB: 128 rows (fc_9)
+constexpr int B16_SUB_BYTES = 2 * B16_CHUNK_BYTES;          // 32 KiB
+constexpr int B16_SUBS = 37;
+constexpr int64_t B16_PACKED_BYTES = (int64_t)CONST_BYTES + (int64_t)B16_SUBS * B16_SUB_BYTES;
 __host__ __device__ constexpr int b16_frag_offset(int n, int slot) { return n * 64 + ((slot ^ ((n >> 2) & 3)) << 4); }
 
 // physical byte offset, inside a chunk image, of the 16-byte slot holding

@@ -83,29 +83,27 @@ __global__ void pack_kernel(const float *__restrict__ P, float *__restrict__ out
     }
 }
 
-// ---- bf16 stream (mlp_layout.h "bf16 inference stream")
-__device__ float bf16_stream_value(const float *P, int step, int c, int n, int kk) {
-    if (step == 0) {
+// ---- bf16 stream (mlp_layout.h "bf16 inference stream"): value of row n, k-value kk (0..31) of chunk c of sub-step `sub`
+__device__ float bf16_stream_value(const float *P, int sub, int c, int n, int kk) {
+    if (sub == 0 || sub == 17) {                       // encoded position into fc_in / fc_5 (pos first, nerf.py:108)
         const int k = 32 * c + kk;
-        return (c < 2 && k < E_POS) ? weight(P, 0, n, k) : 0.0f;
+        return k < E_POS ? weight(P, sub == 0 ? 0 : 5, n, k) : 0.0f;
     }
-    if (step <= 8) return weight(P, 1 + (step - 1) / 2, n, 32 * (((step - 1) % 2) * 4 + c) + kk);
-    if (step == 9) {
-        const int k = 32 * c + kk;
-        return (c < 2 && k < E_POS) ? weight(P, 5, n, k) : 0.0f;
-    }
-    if (step <= 11) return weight(P, 5, n, E_POS + 32 * ((step - 10) * 4 + c) + kk);
-    if (step <= 15) return weight(P, 6 + (step - 12) / 2, n, 32 * (((step - 12) % 2) * 4 + c) + kk);
-    if (step <= 17) return weight(P, 8, n + 1, 32 * ((step - 16) * 4 + c) + kk);
-    if (n >= HALF) return 0.0f;
-    if (step <= 19) return weight(P, 9, n, 32 * ((step - 18) * 4 + c) + kk);
-    return (c == 0 && kk < E_DIR) ? weight(P, 9, n, FEAT + kk) : 0.0f;
+    if (sub <= 16) return weight(P, 1 + (sub - 1) / 4, n, 32 * (2 * ((sub - 1) % 4) + c) + kk);
+    if (sub <= 21) return weight(P, 5, n, E_POS + 32 * (2 * (sub - 18) + c) + kk);
+    if (sub <= 29) return weight(P, 6 + (sub - 22) / 4, n, 32 * (2 * ((sub - 22) % 4) + c) + kk);
+    return weight(P, 8, n + 1, 32 * (2 * (sub - 30) + c) + kk);   // subs 30..33: fc_8 rows 1..256
+}
+// fc_9 (subs 34..36): 128-row chunks, three per sub-step; chunk index ck = 3 (sub - 34) + c is the k-block, 8 = direction
+__device__ float bf16_fc9_value(const float *P, int ck, int n, int kk) {
+    if (ck < 8) return weight(P, 9, n, 32 * ck + kk);
+    return (ck == 8 && kk < E_DIR) ? weight(P, 9, n, FEAT + kk) : 0.0f;
 }
 
 __global__ void pack_bf16_kernel(const float *__restrict__ P, char *__restrict__ out) {
     float *cblock = reinterpret_cast<float *>(out);
     __bf16 *stream = reinterpret_cast<__bf16 *>(out + CONST_BYTES);
-    const int64_t n_bf16 = (int64_t)B16_STEPS * B16_STEP_BYTES / 2;
+    const int64_t n_bf16 = (int64_t)B16_SUBS * B16_SUB_BYTES / 2;
     const int64_t total = CONST_FLOATS + n_bf16;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
@@ -114,15 +112,17 @@ __global__ void pack_bf16_kernel(const float *__restrict__ P, char *__restrict__
             continue;
         }
         const int64_t r = e - CONST_FLOATS;            // bf16 element index in the stream
-        const int step = (int)(r / (B16_STEP_BYTES / 2));
-        const int in_step = (int)(r % (B16_STEP_BYTES / 2));
-        const int c = in_step / (B16_CHUNK_BYTES / 2);
-        const int b = (in_step % (B16_CHUNK_BYTES / 2)) * 2;  // byte offset inside the chunk image
+        const int sub = (int)(r / (B16_SUB_BYTES / 2));
+        const int in_sub = (int)(r % (B16_SUB_BYTES / 2)) * 2;   // byte offset inside the sub-step
+        const int chunk_bytes = sub >= 34 ? B16_HALF_CHUNK_BYTES : B16_CHUNK_BYTES;
+        const int c = in_sub / chunk_bytes;
+        const int b = in_sub % chunk_bytes;                   // byte offset inside the chunk image
         const int n = b >> 6;                                 // row (64 B per row)
         const int slot = ((b & 63) >> 4) ^ ((n >> 2) & 3);    // logical fragment 2s+h
         const int el = (b & 15) >> 1;
         const int kk = 16 * (slot >> 1) + 8 * (el >> 2) + 4 * (slot & 1) + (el & 3);
-        stream[r] = (__bf16)bf16_stream_value(P, step, c, n, kk);
+        stream[r] = (__bf16)(sub >= 34 ? (c < 3 ? bf16_fc9_value(P, 3 * (sub - 34) + c, n, kk) : 0.0f)
+                                       : bf16_stream_value(P, sub, c, n, kk));
     }
 }
 
