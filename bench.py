@@ -452,10 +452,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    # ---- dominant kernel: the fused MLP kernel, two launches per step: coarse pass M = 4096 x 64 and fine pass
-    # M = 4096 x 192.  achieved = algorithmic FLOPs of all its launches in the timed region / their summed
-    # HIP-event durations; ms_per_launch = their mean (what rocprofv3 --stats reports as the kernel's average).
-    durs = [(M, e0.elapsed_time(e1)) for tag, M, e0, e1 in events if tag == "mlp_forward"]
+    # ---- dominant kernel: the fused render pass (sampling + encode + MLP + integral in one kernel), two launches
+    # per step: coarse pass M = 4096 x 64 and fine pass M = 4096 x 192 samples.  achieved = algorithmic MLP FLOPs
+    # of all its launches in the timed region / their summed HIP-event durations (so the in-kernel sampling and
+    # integration count against the fraction); ms_per_launch = their mean (what rocprofv3 --stats reports as the
+    # kernel's average).
+    durs = [(M, e0.elapsed_time(e1)) for tag, M, e0, e1 in events if tag == "render_pass"]
     total_ms = sum(ms for _, ms in durs)
     total_flop = sum(M for M, _ in durs) * MLP_FLOP_PER_SAMPLE
     achieved = total_flop / (total_ms * 1e-3) / 1e12

@@ -140,16 +140,28 @@ int nerf_composite_backward(const float *sigma, const float *radiance, const flo
                             float *g_sigma, float *g_radiance, nerf_stream_t stream);
 
 /* ---- a3 + a12: one VolumeRenderer.render_scene pass (inference) on a ray range,
- * R/renderer/volume_renderer.py:59-169, :192-261 -- the Python batch loop becomes a
- * single enqueue of sample -> query -> integrate over `n` rays.
+ * R/renderer/volume_renderer.py:59-169, :192-261 -- the Python batch loop over
+ * sample_along_rays (ray_samplers/stratified_sampler.py:57-128) -> query_points (scene/primitives/cube.py:39-76)
+ * -> integrate_along_rays (integrators/quadrature_integrator.py:14-67) becomes ONE kernel over `n` rays
+ * (csrc/render_fused.hip) whenever the samples of a few rays tile the 128-sample MLP pass
+ * (nerf_render_is_fused: S = 64, 128, 192, 256, ...; 32 / 96 / 160 with four rays per group): sample points,
+ * directions, delta, sigma and radiance never reach HBM.  Other sample counts run as three launches through
+ * `workspace`.
  *   coarse pass: weights_in = NULL, u2 = u3 = NULL, Sf = 0
  *   fine pass:   weights_in (n,Sc) is mutated in place like a7
- * workspace: nerf_render_workspace_bytes(n, Sc+Sf). */
+ * workspace: nerf_render_workspace_bytes(n, Sc+Sf); may be NULL when nerf_render_is_fused(Sc, Sf, fine).
+ * nerf_render_pass: the same with the optional outputs of a7 -- bin_idx (n,Sf) int64, t (n,S) sorted sample
+ * positions -- for parity checks of the fused kernel (both NULL: identical to nerf_render_rays). */
+int nerf_render_is_fused(int Sc, int Sf, int fine);
 int64_t nerf_render_workspace_bytes(int64_t n, int S);
 int nerf_render_rays(const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc,
                      int Sf, const float *t_bins, float partition_size, float *weights_in,
                      const float *u1, const float *u2, const float *u3, float *rgb,
                      float *weights_out, void *workspace, nerf_stream_t stream);
+int nerf_render_pass(const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc,
+                     int Sf, const float *t_bins, float partition_size, float *weights_in,
+                     const float *u1, const float *u2, const float *u3, float *rgb,
+                     float *weights_out, int64_t *bin_idx, float *t, void *workspace, nerf_stream_t stream);
 
 /* ---- e: draws for ray-sharded rendering / training.  The reference draws with torch.rand / rand_like inside
  * the sampler (R/renderer/ray_samplers/stratified_sampler.py:77,:109; R/renderer/ray_samplers/utils.py:43,:56);

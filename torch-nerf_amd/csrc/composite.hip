@@ -6,17 +6,12 @@
 // forward reads sigma 4 + radiance 12 + delta 4 and writes w 4 bytes per sample
 // (+12 B/ray); backward reads 20 (+4 with g_w) and writes 16.
 #include "common.h"
+#include "render_device.h"
 
 namespace {
 
-__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const double up = __shfl_up(v, off, WAVE);
-        if (lane >= off) v += up;
-    }
-    return v;
-}
+using render::wave_inclusive_scan;
+using render::wave_sum;
 
 // inclusive scan from the high lane downwards: out[l] = sum_{k >= l} v[k]
 __device__ __forceinline__ double wave_inclusive_scan_rev(double v, int lane) {
@@ -25,12 +20,6 @@ __device__ __forceinline__ double wave_inclusive_scan_rev(double v, int lane) {
         const double dn = __shfl_down(v, off, WAVE);
         if (lane + off < WAVE) v += dn;
     }
-    return v;
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
     return v;
 }
 
@@ -46,34 +35,13 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK *WAVE) void composite_fwd_kernel(
     const float *sg = sigma + ray * S;
     const float *dl = delta + ray * S;
     const float *cl = radiance + ray * S * 3;
-    double carry = 0.0;  // sum of tau over all earlier 64-sample steps
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-    for (int s0 = 0; s0 < S; s0 += WAVE) {
-        const int s = s0 + lane;
-        const bool live = s < S;
-        const float tau = live ? sg[s] * dl[s] : 0.0f;  // quadrature_integrator.py:41
-        const double incl = wave_inclusive_scan((double)tau, lane);
-        double excl = __shfl_up(incl, 1, WAVE);
-        if (lane == 0) excl = 0.0;
-        // :44-52  T_i = exp(-cumsum([0, tau])[:-1]) ; the prefix is rounded to fp32 like ATen's
-        const float T = expf(-(float)(carry + excl));
-        const float alpha = 1.0f - expf(-tau);  // :55
-        const float w = T * alpha;              // :58
-        if (live) {
-            weights[ray * S + s] = w;
-            acc0 += w * cl[3 * s + 0];  // :62-65
-            acc1 += w * cl[3 * s + 1];
-            acc2 += w * cl[3 * s + 2];
-        }
-        carry += __shfl(incl, WAVE - 1, WAVE);
-    }
-    acc0 = wave_sum(acc0);
-    acc1 = wave_sum(acc1);
-    acc2 = wave_sum(acc2);
+    float out[3];
+    render::composite_ray(lane, S, [&](int s) { return sg[s]; }, [&](int s) { return dl[s]; },
+                          [&](int s, int c) { return cl[3 * s + c]; }, weights + ray * S, out);
     if (lane == 0) {
-        rgb[3 * ray + 0] = acc0;
-        rgb[3 * ray + 1] = acc1;
-        rgb[3 * ray + 2] = acc2;
+        rgb[3 * ray + 0] = out[0];
+        rgb[3 * ray + 1] = out[1];
+        rgb[3 * ray + 2] = out[2];
     }
 }
 

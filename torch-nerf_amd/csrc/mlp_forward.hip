@@ -20,6 +20,7 @@
 //  * bound: fp32 MFMA (9280 MFMAs = 38.0 MFLOP per 32 samples); HBM traffic 40 B/sample
 #include "common.h"
 #include "mlp_device.h"
+#include "mlp_tile.h"
 
 namespace {
 
@@ -61,7 +62,6 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
 
     const int64_t ntiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES;
     const int64_t MP = padded_rows(M);
-    const int in_w = ENCODED ? E_POS : 3, in_wd = ENCODED ? E_DIR : 3;
 
     // raw inputs of the first tile; later tiles are prefetched one tile ahead
     float raw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -77,135 +77,22 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
     };
     load_raw(blockIdx.x);
 
+    Timeline tl;
 #ifdef X_TIMELINE   // scripts/timeline.py: cycle stamps of workgroup 0, written behind the 3 M colours
-    unsigned long long *tl = reinterpret_cast<unsigned long long *>(rgb_out + 3 * M);
-    int tl_n = 0;
-#define TS() do { if (blockIdx.x == 0 && tid == 0) tl[tl_n++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define TS() do {} while (0)
+    tl.buf = reinterpret_cast<unsigned long long *>(rgb_out + 3 * M);
+    tl.n = 0;
+    tl.on = blockIdx.x == 0 && tid == 0;
 #endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        TS();
+        tl.stamp();
         const int64_t m = tile * TILE_SAMPLES + wave * 32 + i;
         const bool valid = m < M;
         const int64_t mc = valid ? m : M - 1;
 
-        // ---- encodings, straight into B-fragment layout: reg r <-> feature 32 kb + (r&3) + 8 (r>>2) + 4 h
-        f32x16 pe[2], de;
-        if (ENCODED) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
-                pe[0][r] = pos[mc * in_w + k];
-                pe[1][r] = (32 + k < E_POS) ? pos[mc * in_w + 32 + k] : 0.0f;
-                de[r] = (k < E_DIR) ? dir[mc * in_wd + k] : 0.0f;
-            }
-        } else if (__builtin_expect(__any(encoding_needs_exact(raw)), 0)) {
-            // some lane of this wave has a huge (or non-finite) coordinate: library sin/cos for the tile
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
-                pe[0][r] = enc_feature<true>(k, raw[0], raw[1], raw[2], E_POS);
-                pe[1][r] = enc_feature<true>(32 + k, raw[0], raw[1], raw[2], E_POS);
-                de[r] = enc_feature<true>(k, raw[3], raw[4], raw[5], E_DIR);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
-                pe[0][r] = enc_feature<false>(k, raw[0], raw[1], raw[2], E_POS);
-                pe[1][r] = enc_feature<false>(32 + k, raw[0], raw[1], raw[2], E_POS);
-                de[r] = enc_feature<false>(k, raw[3], raw[4], raw[5], E_DIR);
-            }
-        }
-        if (!ENCODED) {
-            load_raw(tile + gridDim.x);  // next tile's points: a whole tile of MFMAs hides the latency
-        }
-
-        f32x16 acc[8], act[8];
-
-        // ---- fc_in (nerf.py:102): one pair = the two 32-wide halves of the encoded position
-        TS();
-        {
-            const char *w = lds + pipe.acquire();
-            if (SAVE) {
-                save_plane<2>(saved + pl_pe(MP), 64, m, h, pe);
-                save_plane<1>(saved + pl_de(MP), 32, m, h, &de);
-            }
-            load_bias<8>(acc, cb + CB_BIAS, h);
-            mma_pair<8>(acc, pe[0], pe[1], w, offq, pipe);
-        }
-
-        // ---- fc_1 .. fc_8 (nerf.py:103-113); skip connection at fc_5 (pos FIRST, :108).
-        // The ReLU / record / bias section of layer l-1 sits AFTER the acquire of layer l's first
-        // pair, so its vector-ALU work and stores overlap the DMA wait and the first MFMAs.
-        float sigma_pre = 0.0f;
-        for (int l = 1; l <= 8; ++l) {
-            TS();
-            const char *w = lds + pipe.acquire();
-            TS();
-#pragma unroll
-            for (int fb = 0; fb < 8; ++fb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) act[fb][r] = relu1(acc[fb][r]);  // ReLU of layer l-1
-            if (SAVE) {
-                save_plane<8>(saved + pl_h(MP, l - 1), 256, m, h, act);
-                save_mask<8>(saved + pl_masks(MP) + (int64_t)(l - 1) * MP * 8, m, h, act);
-            }
-            if (l == 8) sigma_pre = half_dot<8>(cb + CB_W8ROW0, act, h);  // density row of fc_8
-            load_bias<8>(acc, l < 8 ? cb + CB_BIAS + l * 256 : cb + CB_BIAS8, h);
-            TS();
-            if (l == 5) {
-                mma_pair<8>(acc, pe[0], pe[1], w, offq, pipe);
-                w = lds + pipe.acquire();
-            }
-            mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
-            TS();
-#pragma unroll
-            for (int pr = 1; pr < 4; ++pr) {
-                w = lds + pipe.acquire();
-                mma_pair<8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
-            }
-        }
-
-        // ---- fc_9 on cat([x[:,1:], view_dir]) -- features FIRST (:116-118); fc_8 has no ReLU (:113)
-        TS();
-        {
-            const char *w = lds + pipe.acquire();
-#pragma unroll
-            for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];
-            if (SAVE) save_plane<8>(saved + pl_y8(MP), 256, m, h, act);
-            load_bias<4>(acc, cb + CB_BIAS9, h);
-            mma_pair<4>(acc, act[0], act[1], w, offq, pipe);
-#pragma unroll
-            for (int pr = 1; pr < 4; ++pr) {
-                w = lds + pipe.acquire();
-                mma_pair<4>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
-            }
-            w = lds + pipe.acquire();  // direction chunk + filler chunk (not multiplied)
-            mma_chunk<4, 0, 16>(acc, de, w, offq, &pipe);
-            pipe.issue_done();
-        }
-        TS();
-        sigma_pre += __shfl_xor(sigma_pre, 32, WAVE);
-        const float sigma = fmaxf(sigma_pre + cb[CB_SCALARS], 0.0f);  // relu(x[:,0]) (:115)
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[fb][r] = relu1(acc[fb][r]);
-        if (SAVE) {
-            save_plane<4>(saved + pl_h9(MP), 128, m, h, acc);
-            save_mask<4>(saved + pl_masks(MP) + (int64_t)8 * MP * 8, m, h, acc);
-        }
-
-        // ---- fc_out + sigmoid (:119) on the vector ALU: 3 x 128 MACs per sample
-        float y[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float p = half_dot<4>(cb + CB_WOUT + c * HALF, acc, h);
-            p += __shfl_xor(p, 32, WAVE);
-            y[c] = 1.0f / (1.0f + expf(-(p + cb[CB_SCALARS + 1 + c])));
-        }
+        float sigma, y[3];
+        forward_tile<ENCODED, SAVE>(raw, pos, dir, mc, m, MP, h, pipe, lds, cb, offq, saved,
+                                    [&]() { load_raw(tile + gridDim.x); },  // next tile's points: a whole tile of MFMAs hides the latency
+                                    tl, sigma, y);
         if (valid && h == 0) {
             sigma_out[m] = sigma;
             rgb_out[3 * m + 0] = y[0];

@@ -1,0 +1,146 @@
+// One 128-sample tile of the fused encode + NeRF forward (a8 + a9 + a10), shared by the plain MLP kernel
+// (mlp_forward.hip) and the fused render pass (render_fused.hip).  See mlp_forward.hip for the structure.
+#pragma once
+#include "mlp_device.h"
+
+namespace mlp {
+
+// X_TIMELINE builds (scripts/timeline.py): cycle stamps of one lane, written to a buffer the kernel provides
+struct Timeline {
+#ifdef X_TIMELINE
+    unsigned long long *buf;
+    int n;
+    bool on;
+    __device__ __forceinline__ void stamp() { if (on) buf[n++] = __builtin_readcyclecounter(); }
+#else
+    __device__ __forceinline__ void stamp() {}
+#endif
+};
+#define NERF_TS() tl.stamp()
+
+// Inputs of this lane's sample: raw[0..2] position, raw[3..5] direction (ENCODED: read from pos/dir rows mc instead).
+// `after_encode()` runs once the raw inputs are consumed (the caller prefetches the next tile's there).
+// Outputs: sigma and the three colours of sample m, valid in the lanes of both halves.
+template <bool ENCODED, bool SAVE, class AfterEncode>
+__device__ __forceinline__ void forward_tile(const float (&raw)[6], const float *__restrict__ pos,
+                                             const float *__restrict__ dir, int64_t mc, int64_t m, int64_t MP,
+                                             int h, Pipe &pipe, const char *lds, const float *cb, const int (&offq)[4],
+                                             float *__restrict__ saved, AfterEncode after_encode, Timeline &tl,
+                                             float &sigma_result, float (&y)[3]) {
+    const int in_w = ENCODED ? E_POS : 3, in_wd = ENCODED ? E_DIR : 3;
+    // ---- encodings, straight into B-fragment layout: reg r <-> feature 32 kb + (r&3) + 8 (r>>2) + 4 h
+    f32x16 pe[2], de;
+    if (ENCODED) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+            pe[0][r] = pos[mc * in_w + k];
+            pe[1][r] = (32 + k < E_POS) ? pos[mc * in_w + 32 + k] : 0.0f;
+            de[r] = (k < E_DIR) ? dir[mc * in_wd + k] : 0.0f;
+        }
+    } else if (__builtin_expect(__any(encoding_needs_exact(raw)), 0)) {
+        // some lane of this wave has a huge (or non-finite) coordinate: library sin/cos for the tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+            pe[0][r] = enc_feature<true>(k, raw[0], raw[1], raw[2], E_POS);
+            pe[1][r] = enc_feature<true>(32 + k, raw[0], raw[1], raw[2], E_POS);
+            de[r] = enc_feature<true>(k, raw[3], raw[4], raw[5], E_DIR);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+            pe[0][r] = enc_feature<false>(k, raw[0], raw[1], raw[2], E_POS);
+            pe[1][r] = enc_feature<false>(32 + k, raw[0], raw[1], raw[2], E_POS);
+            de[r] = enc_feature<false>(k, raw[3], raw[4], raw[5], E_DIR);
+        }
+    }
+    after_encode();
+
+    f32x16 acc[8], act[8];
+
+    // ---- fc_in (nerf.py:102): one pair = the two 32-wide halves of the encoded position
+    NERF_TS();
+    {
+        const char *w = lds + pipe.acquire();
+        if (SAVE) {
+            save_plane<2>(saved + pl_pe(MP), 64, m, h, pe);
+            save_plane<1>(saved + pl_de(MP), 32, m, h, &de);
+        }
+        load_bias<8>(acc, cb + CB_BIAS, h);
+        mma_pair<8>(acc, pe[0], pe[1], w, offq, pipe);
+    }
+
+    // ---- fc_1 .. fc_8 (nerf.py:103-113); skip connection at fc_5 (pos FIRST, :108).
+    // The ReLU / record / bias section of layer l-1 sits AFTER the acquire of layer l's first
+    // pair, so its vector-ALU work and stores overlap the DMA wait and the first MFMAs.
+    float sigma_pre = 0.0f;
+    for (int l = 1; l <= 8; ++l) {
+        NERF_TS();
+        const char *w = lds + pipe.acquire();
+        NERF_TS();
+#pragma unroll
+        for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) act[fb][r] = relu1(acc[fb][r]);  // ReLU of layer l-1
+        if (SAVE) {
+            save_plane<8>(saved + pl_h(MP, l - 1), 256, m, h, act);
+            save_mask<8>(saved + pl_masks(MP) + (int64_t)(l - 1) * MP * 8, m, h, act);
+        }
+        if (l == 8) sigma_pre = half_dot<8>(cb + CB_W8ROW0, act, h);  // density row of fc_8
+        load_bias<8>(acc, l < 8 ? cb + CB_BIAS + l * 256 : cb + CB_BIAS8, h);
+        NERF_TS();
+        if (l == 5) {
+            mma_pair<8>(acc, pe[0], pe[1], w, offq, pipe);
+            w = lds + pipe.acquire();
+        }
+        mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
+        NERF_TS();
+#pragma unroll
+        for (int pr = 1; pr < 4; ++pr) {
+            w = lds + pipe.acquire();
+            mma_pair<8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
+        }
+    }
+
+    // ---- fc_9 on cat([x[:,1:], view_dir]) -- features FIRST (:116-118); fc_8 has no ReLU (:113)
+    NERF_TS();
+    {
+        const char *w = lds + pipe.acquire();
+#pragma unroll
+        for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];
+        if (SAVE) save_plane<8>(saved + pl_y8(MP), 256, m, h, act);
+        load_bias<4>(acc, cb + CB_BIAS9, h);
+        mma_pair<4>(acc, act[0], act[1], w, offq, pipe);
+#pragma unroll
+        for (int pr = 1; pr < 4; ++pr) {
+            w = lds + pipe.acquire();
+            mma_pair<4>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
+        }
+        w = lds + pipe.acquire();  // direction chunk + filler chunk (not multiplied)
+        mma_chunk<4, 0, 16>(acc, de, w, offq, &pipe);
+        pipe.issue_done();
+    }
+    NERF_TS();
+    sigma_pre += __shfl_xor(sigma_pre, 32, WAVE);
+    sigma_result = fmaxf(sigma_pre + cb[CB_SCALARS], 0.0f);  // relu(x[:,0]) (:115)
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[fb][r] = relu1(acc[fb][r]);
+    if (SAVE) {
+        save_plane<4>(saved + pl_h9(MP), 128, m, h, acc);
+        save_mask<4>(saved + pl_masks(MP) + (int64_t)8 * MP * 8, m, h, acc);
+    }
+
+    // ---- fc_out + sigmoid (:119) on the vector ALU: 3 x 128 MACs per sample
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float p = half_dot<4>(cb + CB_WOUT + c * HALF, acc, h);
+        p += __shfl_xor(p, 32, WAVE);
+        y[c] = 1.0f / (1.0f + expf(-(p + cb[CB_SCALARS + 1 + c])));
+    }
+}
+
+}  // namespace mlp

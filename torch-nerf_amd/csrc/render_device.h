@@ -1,0 +1,351 @@
+// Per-ray device code shared by the stand-alone sampling / integral kernels (sampling.hip, composite.hip) and
+// the fused render pass (render_fused.hip): ONE wavefront works on ONE ray, its sample row lives in LDS.
+// Everything that decides an integer in the reference (the pdf normaliser, the cdf, the bin search) follows
+// ATen's CPU evaluation order literally, with separately rounded fp32 operations, so that bin indices are
+// bit-identical to the reference's CPU path whichever kernel runs this code.
+#pragma once
+#include "common.h"
+
+// X_FUSED_TIMELINE builds: RD_STAMP() records the cycle counter of thread 0 of workgroup 0 (render_fused.hip)
+#ifndef RD_STAMP
+#define RD_STAMP() do {} while (0)
+#endif
+
+namespace render {
+
+// LDS traffic of one wavefront is processed in program order, so a row written by the wave is readable by any
+// of its lanes afterwards; only the compiler has to be kept from reordering across the phase boundary.
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int ceil_log2_i(int x) {
+    if (x <= 2) return 1;
+    return 32 - __builtin_clz((unsigned)(x - 1));
+}
+
+// ATen's CPU sum over a contiguous last dimension (SumKernel.cpp: vectorized_inner_sum ->
+// row_sum -> multi_row_sum, 8-wide vectors, 4 interleaved accumulators, 4-level cascade).
+// Lane l < 8 plays vector lane l and returns its partial; the caller finishes on lane 0.
+__device__ inline float aten_sum_vector_lane(const float *row, int size0, int l) {
+    constexpr int VEC = 8, ILP = 4, LEVELS = 4;
+    const int vec_size = size0 / VEC;
+    const int size_ilp = vec_size / ILP;
+    int level_power = ceil_log2_i(size_ilp) / LEVELS;
+    if (level_power < 4) level_power = 4;
+    const int level_step = 1 << level_power;
+    const int level_mask = level_step - 1;
+    float acc[LEVELS][ILP];
+#pragma unroll
+    for (int j = 0; j < LEVELS; ++j)
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) acc[j][k] = 0.0f;
+    int i = 0;
+    for (; i + level_step <= size_ilp;) {
+        for (int j = 0; j < level_step; ++j, ++i) {
+#pragma unroll
+            for (int k = 0; k < ILP; ++k)
+                acc[0][k] = __fadd_rn(acc[0][k], row[(i * ILP + k) * VEC + l]);
+        }
+        bool stop = false;
+#pragma unroll
+        for (int j = 1; j < LEVELS; ++j) {
+            if (!stop) {
+#pragma unroll
+                for (int k = 0; k < ILP; ++k) {
+                    acc[j][k] = __fadd_rn(acc[j][k], acc[j - 1][k]);
+                    acc[j - 1][k] = 0.0f;
+                }
+                const int mask = level_mask << (j * level_power);
+                if ((i & mask) != 0) stop = true;
+            }
+        }
+    }
+    for (; i < size_ilp; ++i) {
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) acc[0][k] = __fadd_rn(acc[0][k], row[(i * ILP + k) * VEC + l]);
+    }
+#pragma unroll
+    for (int j = 1; j < LEVELS; ++j)
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) acc[0][k] = __fadd_rn(acc[0][k], acc[j][k]);
+    // row_sum tail: whole vectors left over after the (-1, ILP) view
+    for (int v = size_ilp * ILP; v < vec_size; ++v) acc[0][0] = __fadd_rn(acc[0][0], row[v * VEC + l]);
+#pragma unroll
+    for (int k = 1; k < ILP; ++k) acc[0][0] = __fadd_rn(acc[0][0], acc[0][k]);
+    return acc[0][0];
+}
+
+// LDS floats one ray needs besides its S sorted sample positions: unsorted positions, weights / pdf, cdf, partials
+__host__ __device__ constexpr int hierarchical_scratch_floats(int Sc, int Sf) {
+    return (((Sc + Sf) + 3) & ~3) + 2 * ((Sc + 3) & ~3) + 16;   // every row starts 16-byte aligned
+}
+
+// stratified_sampler.py:107-109 (coarse branch): t = t_bins + partition_size * U1, into the LDS row `t`
+__device__ __forceinline__ void stratified_ray(int lane, int S, const float *__restrict__ t_bins, float ps,
+                                               const float *__restrict__ u1_row, float *t) {
+    for (int s = lane; s < S; s += WAVE) t[s] = __fadd_rn(t_bins[s], __fmul_rn(ps, u1_row[s]));
+    wave_fence();
+}
+
+// ---- torch.sort of one row of S floats (ascending) as a rank sort: out[rank(e)] = in[e], rank(e) = number of
+// elements that sort before e.  The sorted VALUES do not depend on how ties are ordered, but ranks must be
+// distinct, so ties are broken by position: element j sorts before e iff (key(in[j]), j) < (key(in[e]), e) with
+// key() the usual order-preserving map of float bits to unsigned -- ONE 64-bit unsigned compare per pair.  A lane
+// owns K elements per sweep (e = e0 + lane + 64 k) and ranks them in one walk over the row, four positions per
+// LDS read: for S = 192, 48 broadcast reads and 48 x 4 x 3 compares per lane.  (-0.0 sorts before +0.0 here,
+// torch.sort leaves them in input order: the only difference, and not one in the VALUE sequence's use.)
+__device__ __forceinline__ unsigned sort_key(float v) {
+    const unsigned b = __float_as_uint(v);
+    return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+
+template <int K>
+__device__ __forceinline__ void rank_sort_sweep(int lane, int S, int e0, const float *in, float *out) {
+    float x[K];
+    unsigned long long key[K];
+    int rank[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = e0 + lane + WAVE * k;
+        x[k] = e < S ? in[e] : 0.0f;
+        key[k] = ((unsigned long long)sort_key(x[k]) << 32) | (unsigned)e;
+        rank[k] = 0;
+    }
+    const int S4 = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) ? (S & ~3) : 0;
+#pragma unroll 2
+    for (int j = 0; j < S4; j += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(in + j);
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned long long kj = ((unsigned long long)sort_key(xs[c]) << 32) | (unsigned)(j + c);
+#pragma unroll
+            for (int k = 0; k < K; ++k) rank[k] += kj < key[k] ? 1 : 0;
+        }
+    }
+    for (int j = S4; j < S; ++j) {
+        const unsigned long long kj = ((unsigned long long)sort_key(in[j]) << 32) | (unsigned)j;
+#pragma unroll
+        for (int k = 0; k < K; ++k) rank[k] += kj < key[k] ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (e0 + lane + WAVE * k < S) out[rank[k]] = x[k];
+}
+
+// The common case has no ties: then rank(e) = #{j : in[j] < in[e]} -- one full-rate float compare per pair (the
+// 64-bit compare of the exact sweep runs at a quarter of that).  Ties (or NaNs) make two elements claim one slot
+// and leave another empty; the row is therefore pre-filled with NaN, and if any slot is still NaN after the
+// scatter the whole row is redone by the exact sweep.
+template <int K>
+__device__ __forceinline__ bool rank_sort_sweep_fast(int lane, int S, int e0, const float *in, float *out) {
+    float x[K];
+    int rank[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = e0 + lane + WAVE * k;
+        x[k] = e < S ? in[e] : 0.0f;
+        rank[k] = 0;
+    }
+    const int S4 = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) ? (S & ~3) : 0;
+#pragma unroll 2
+    for (int j = 0; j < S4; j += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(in + j);
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < K; ++k) rank[k] += xs[c] < x[k] ? 1 : 0;
+    }
+    for (int j = S4; j < S; ++j) {
+        const float xj = in[j];
+#pragma unroll
+        for (int k = 0; k < K; ++k) rank[k] += xj < x[k] ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (e0 + lane + WAVE * k < S) out[rank[k]] = x[k];
+    return true;
+}
+
+__device__ __forceinline__ void rank_sort_row(int lane, int S, const float *in, float *out) {
+    if (S <= 4 * WAVE) {   // one sweep covers the row: try the tie-free fast path first
+        const float hole = __uint_as_float(0x7fc00000u);
+        for (int e = lane; e < S; e += WAVE) out[e] = hole;
+        wave_fence();
+        if (S > 3 * WAVE) rank_sort_sweep_fast<4>(lane, S, 0, in, out);
+        else if (S > 2 * WAVE) rank_sort_sweep_fast<3>(lane, S, 0, in, out);
+        else if (S > WAVE) rank_sort_sweep_fast<2>(lane, S, 0, in, out);
+        else rank_sort_sweep_fast<1>(lane, S, 0, in, out);
+        wave_fence();
+        bool bad = false;
+        for (int e = lane; e < S; e += WAVE) bad |= out[e] != out[e];
+        if (!__any(bad)) return;
+        wave_fence();
+    }
+    for (int e0 = 0; e0 < S; e0 += 4 * WAVE) {
+        const int left = S - e0;
+        if (left > 3 * WAVE) rank_sort_sweep<4>(lane, S, e0, in, out);
+        else if (left > 2 * WAVE) rank_sort_sweep<3>(lane, S, e0, in, out);
+        else if (left > WAVE) rank_sort_sweep<2>(lane, S, e0, in, out);
+        else rank_sort_sweep<1>(lane, S, e0, in, out);
+    }
+}
+
+// stratified_sampler.py:57-90 + ray_samplers/utils.py:8-58 for one ray: floor the coarse weights in place,
+// inverse-CDF pick of Sf bins, in-bin jitter, sort(cat[coarse, fine]) into the LDS row `t_srt` (Sc + Sf floats).
+// `scratch`: hierarchical_scratch_floats(Sc, Sf) LDS floats private to this wavefront.
+__device__ inline void hierarchical_ray(int lane, int Sc, int Sf, const float *__restrict__ t_bins, float ps,
+                                        float *__restrict__ weights_row, const float *__restrict__ u1_row,
+                                        const float *__restrict__ u2_row, const float *__restrict__ u3_row,
+                                        int64_t *__restrict__ bin_idx_row, float *scratch, float *t_srt) {
+    const int S = Sc + Sf;
+    float *t_raw = scratch;                  // S   coarse then fine, unsorted
+    float *w = t_raw + ((S + 3) & ~3);       // Sc  weights + 1e-5, then pdf
+    float *cdf = w + ((Sc + 3) & ~3);        // Sc
+    float *part = cdf + ((Sc + 3) & ~3);     // 8 partial sums + 1 normaliser
+    // utils.py:31  weights += 1e-5 (in place, visible to the caller)
+    for (int s = lane; s < Sc; s += WAVE) {
+        const float v = __fadd_rn(weights_row[s], 1e-5f);
+        weights_row[s] = v;
+        w[s] = v;
+        // stratified_sampler.py:77  new coarse jitter
+        t_raw[s] = __fadd_rn(t_bins[s], __fmul_rn(ps, u1_row[s]));
+    }
+    wave_fence();
+    RD_STAMP();
+    // utils.py:32  normalizer = torch.sum(weights, -1) in ATen's order
+    if (lane < 8) part[lane] = aten_sum_vector_lane(w, Sc, lane);
+    wave_fence();
+    if (lane == 0) {
+        float fin = 0.0f;
+        for (int k = (Sc / 8) * 8; k < Sc; ++k) fin = __fadd_rn(fin, w[k]);
+        for (int l = 0; l < 8; ++l) fin = __fadd_rn(fin, part[l]);
+        part[8] = fin;
+    }
+    wave_fence();
+    const float norm = part[8];
+    for (int s = lane; s < Sc; s += WAVE) w[s] = __fdiv_rn(w[s], norm);  // utils.py:33
+    wave_fence();
+    RD_STAMP();
+    // utils.py:36-40  cdf = [0, cumsum(pdf)[:-1]] ; ATen CPU cumsum: ONE double accumulator walking the row,
+    // every prefix rounded to fp32.  The chain of additions is sequential by definition (a parallel scan
+    // rounds differently once the pdf spans more than ~2^29); what need not be sequential is the memory traffic:
+    // every lane takes one pdf value into a register, the chain reads them with v_readlane (wave-uniform, so all
+    // lanes run the same chain and lane l simply keeps prefix l), and the cdf row is written once at the end.
+    {
+        double run = 0.0;
+        for (int base = 0; base < Sc; base += WAVE) {
+            const float mine = (base + lane < Sc) ? w[base + lane] : 0.0f;
+            float keep = 0.0f;   // cdf[base + lane] = sum of pdf[0 .. base + lane - 1]
+            const int cnt = (Sc - base) < WAVE ? (Sc - base) : WAVE;
+            if (cnt == WAVE) {
+#pragma unroll
+                for (int k = 0; k < WAVE; ++k) {
+                    if (lane == k) keep = (float)run;
+                    run += (double)__shfl(mine, k, WAVE);
+                }
+            } else {
+                for (int k = 0; k < cnt; ++k) {
+                    if (lane == k) keep = (float)run;
+                    run += (double)__shfl(mine, k, WAVE);
+                }
+            }
+            if (base + lane < Sc) cdf[base + lane] = keep;
+        }
+    }
+    wave_fence();
+    RD_STAMP();
+    // utils.py:43-56  searchsorted(right=True) - 1, gather, in-bin jitter.  searchsorted(right=True) = the number of
+    // cdf entries <= y; the cdf is non-decreasing (prefix sums of a positive pdf), so the count is found by
+    // descending power-of-two steps -- branch-free, two fine samples per lane side by side (their LDS reads
+    // overlap), the draws requested before the first probe.
+    {
+        int top = 1;
+        while (2 * top <= Sc) top *= 2;
+        for (int f0 = 0; f0 < Sf; f0 += 2 * WAVE) {
+            const int fa = f0 + lane, fb = fa + WAVE;
+            const bool has_a = fa < Sf, has_b = fb < Sf;
+            const float ya = has_a ? u2_row[fa] : 0.0f, yb = has_b ? u2_row[fb] : 0.0f;
+            const float ja = has_a ? u3_row[fa] : 0.0f, jb = has_b ? u3_row[fb] : 0.0f;
+            int pa = 0, pb = 0;   // entries known to be <= y
+            for (int step = top; step > 0; step >>= 1) {
+                const int na = pa + step, nb = pb + step;
+                const float ca = cdf[(na <= Sc ? na : Sc) - 1], cb2 = cdf[(nb <= Sc ? nb : Sc) - 1];
+                if (na <= Sc && ca <= ya) pa = na;
+                if (nb <= Sc && cb2 <= yb) pb = nb;
+            }
+            if (has_a) {
+                int k = pa - 1;
+                if (bin_idx_row) bin_idx_row[fa] = (int64_t)k;
+                if (k < 0) k = 0;
+                t_raw[Sc + fa] = __fadd_rn(t_bins[k], __fmul_rn(ps, ja));
+            }
+            if (has_b) {
+                int k = pb - 1;
+                if (bin_idx_row) bin_idx_row[fb] = (int64_t)k;
+                if (k < 0) k = 0;
+                t_raw[Sc + fb] = __fadd_rn(t_bins[k], __fmul_rn(ps, jb));
+            }
+        }
+    }
+    wave_fence();
+    RD_STAMP();
+    // stratified_sampler.py:87-90  sort(cat[coarse, fine])
+    rank_sort_row(lane, S, t_raw, t_srt);
+    wave_fence();
+    RD_STAMP();
+}
+
+// ---- quadrature_integrator.py:41-65 for one ray: lane = sample, 64 samples per step.  The exclusive prefix sum of
+// sigma * delta is a wave-level scan with lane shuffles in double (ATen's CPU cumsum accumulates in double),
+// carried across steps.
+__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const double up = __shfl_up(v, off, WAVE);
+        if (lane >= off) v += up;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// sigma(s), delta(s), radiance(s, c) are accessors (global rows in composite.hip, LDS rows in the fused pass);
+// weights_row is written for s < S; the three colour sums come back in all lanes.
+template <class Sigma, class Delta, class Radiance>
+__device__ __forceinline__ void composite_ray(int lane, int S, Sigma sigma, Delta delta, Radiance radiance,
+                                              float *__restrict__ weights_row, float (&rgb)[3]) {
+    double carry = 0.0;  // sum of tau over all earlier 64-sample steps
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    for (int s0 = 0; s0 < S; s0 += WAVE) {
+        const int s = s0 + lane;
+        const bool live = s < S;
+        const float tau = live ? sigma(s) * delta(s) : 0.0f;  // quadrature_integrator.py:41
+        const double incl = wave_inclusive_scan((double)tau, lane);
+        double excl = __shfl_up(incl, 1, WAVE);
+        if (lane == 0) excl = 0.0;
+        // :44-52  T_i = exp(-cumsum([0, tau])[:-1]) ; the prefix is rounded to fp32 like ATen's
+        const float T = expf(-(float)(carry + excl));
+        const float alpha = 1.0f - expf(-tau);  // :55
+        const float w = T * alpha;              // :58
+        if (live) {
+            weights_row[s] = w;
+            acc0 += w * radiance(s, 0);  // :62-65
+            acc1 += w * radiance(s, 1);
+            acc2 += w * radiance(s, 2);
+        }
+        carry += __shfl(incl, WAVE - 1, WAVE);
+    }
+    rgb[0] = wave_sum(acc0);
+    rgb[1] = wave_sum(acc1);
+    rgb[2] = wave_sum(acc2);
+}
+
+}  // namespace render

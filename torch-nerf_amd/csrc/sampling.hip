@@ -7,65 +7,11 @@
 // HBM traffic per ray: u1/u2/u3 in, pts+dirs+delta out (28 B/sample) -- bandwidth
 // bound, tiny next to the MLP.
 #include "common.h"
+#include "render_device.h"
 
 namespace {
 
-__device__ __forceinline__ int ceil_log2_i(int x) {
-    if (x <= 2) return 1;
-    return 32 - __builtin_clz((unsigned)(x - 1));
-}
-
-// ATen's CPU sum over a contiguous last dimension (SumKernel.cpp: vectorized_inner_sum ->
-// row_sum -> multi_row_sum, 8-wide vectors, 4 interleaved accumulators, 4-level cascade).
-// Lane l < 8 plays vector lane l and returns its partial; the caller finishes on lane 0.
-__device__ float aten_sum_vector_lane(const float *row, int size0, int l) {
-    constexpr int VEC = 8, ILP = 4, LEVELS = 4;
-    const int vec_size = size0 / VEC;
-    const int size_ilp = vec_size / ILP;
-    int level_power = ceil_log2_i(size_ilp) / LEVELS;
-    if (level_power < 4) level_power = 4;
-    const int level_step = 1 << level_power;
-    const int level_mask = level_step - 1;
-    float acc[LEVELS][ILP];
-#pragma unroll
-    for (int j = 0; j < LEVELS; ++j)
-#pragma unroll
-        for (int k = 0; k < ILP; ++k) acc[j][k] = 0.0f;
-    int i = 0;
-    for (; i + level_step <= size_ilp;) {
-        for (int j = 0; j < level_step; ++j, ++i) {
-#pragma unroll
-            for (int k = 0; k < ILP; ++k)
-                acc[0][k] = __fadd_rn(acc[0][k], row[(i * ILP + k) * VEC + l]);
-        }
-        bool stop = false;
-#pragma unroll
-        for (int j = 1; j < LEVELS; ++j) {
-            if (!stop) {
-#pragma unroll
-                for (int k = 0; k < ILP; ++k) {
-                    acc[j][k] = __fadd_rn(acc[j][k], acc[j - 1][k]);
-                    acc[j - 1][k] = 0.0f;
-                }
-                const int mask = level_mask << (j * level_power);
-                if ((i & mask) != 0) stop = true;
-            }
-        }
-    }
-    for (; i < size_ilp; ++i) {
-#pragma unroll
-        for (int k = 0; k < ILP; ++k) acc[0][k] = __fadd_rn(acc[0][k], row[(i * ILP + k) * VEC + l]);
-    }
-#pragma unroll
-    for (int j = 1; j < LEVELS; ++j)
-#pragma unroll
-        for (int k = 0; k < ILP; ++k) acc[0][k] = __fadd_rn(acc[0][k], acc[j][k]);
-    // row_sum tail: whole vectors left over after the (-1, ILP) view
-    for (int v = size_ilp * ILP; v < vec_size; ++v) acc[0][0] = __fadd_rn(acc[0][0], row[v * VEC + l]);
-#pragma unroll
-    for (int k = 1; k < ILP; ++k) acc[0][0] = __fadd_rn(acc[0][0], acc[0][k]);
-    return acc[0][0];
-}
+using render::wave_fence;
 
 // stratified_sampler.py:112-126 -- delta, sample points, repeated directions
 __device__ __forceinline__ void write_samples(const float *t, int S, int lane, int64_t ray,
@@ -95,10 +41,8 @@ __global__ __launch_bounds__(WAVE) void stratified_kernel(const float *ray_o, co
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x;
     for (int64_t ray = blockIdx.x; ray < n; ray += gridDim.x) {
-        __syncthreads();
-        for (int s = lane; s < S; s += WAVE)
-            sm[s] = __fadd_rn(t_bins[s], __fmul_rn(ps, u1[ray * S + s]));  // :109
-        __syncthreads();
+        wave_fence();   // the previous ray's row has been written out
+        render::stratified_ray(lane, S, t_bins, ps, u1 + ray * S, sm);  // :109
         write_samples(sm, S, lane, ray, ray_o, ray_d, t_out, pts, dirs, delta);
     }
 }
@@ -109,72 +53,13 @@ __global__ __launch_bounds__(WAVE) void hierarchical_kernel(
     float *pts, float *dirs, float *delta) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int S = Sc + Sf;
-    float *t_raw = sm;           // S   coarse then fine, unsorted
-    float *t_srt = t_raw + S;    // S   sorted
-    float *w = t_srt + S;        // Sc  weights + 1e-5, then pdf
-    float *cdf = w + Sc;         // Sc
-    float *part = cdf + Sc;      // 8 partial sums + 1 normaliser
+    float *t_srt = sm;           // S sorted positions; the per-ray scratch rows follow
+    float *scratch = sm + ((S + 3) & ~3);
     const int lane = threadIdx.x;
     for (int64_t ray = blockIdx.x; ray < n; ray += gridDim.x) {
-        __syncthreads();
-        // utils.py:31  weights += 1e-5 (in place, visible to the caller)
-        for (int s = lane; s < Sc; s += WAVE) {
-            const float v = __fadd_rn(weights[ray * Sc + s], 1e-5f);
-            weights[ray * Sc + s] = v;
-            w[s] = v;
-            // stratified_sampler.py:77  new coarse jitter
-            t_raw[s] = __fadd_rn(t_bins[s], __fmul_rn(ps, u1[ray * Sc + s]));
-        }
-        __syncthreads();
-        // utils.py:32  normalizer = torch.sum(weights, -1) in ATen's order
-        if (lane < 8) part[lane] = aten_sum_vector_lane(w, Sc, lane);
-        __syncthreads();
-        if (lane == 0) {
-            float fin = 0.0f;
-            for (int k = (Sc / 8) * 8; k < Sc; ++k) fin = __fadd_rn(fin, w[k]);
-            for (int l = 0; l < 8; ++l) fin = __fadd_rn(fin, part[l]);
-            part[8] = fin;
-        }
-        __syncthreads();
-        const float norm = part[8];
-        for (int s = lane; s < Sc; s += WAVE) w[s] = __fdiv_rn(w[s], norm);  // utils.py:33
-        __syncthreads();
-        // utils.py:36-40  cdf = [0, cumsum(pdf)[:-1]] ; ATen CPU cumsum: double accumulator,
-        // every prefix rounded to fp32
-        if (lane == 0) {
-            double run = 0.0;
-            cdf[0] = 0.0f;
-            for (int s = 0; s + 1 < Sc; ++s) {
-                run += (double)w[s];
-                cdf[s + 1] = (float)run;
-            }
-        }
-        __syncthreads();
-        // utils.py:43-56  searchsorted(right=True) - 1, gather, in-bin jitter
-        for (int f = lane; f < Sf; f += WAVE) {
-            const float y = u2[ray * Sf + f];
-            int lo = 0, hi = Sc;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (cdf[mid] <= y) lo = mid + 1; else hi = mid;
-            }
-            int k = lo - 1;
-            if (bin_idx) bin_idx[ray * Sf + f] = (int64_t)k;
-            if (k < 0) k = 0;
-            t_raw[Sc + f] = __fadd_rn(t_bins[k], __fmul_rn(ps, u3[ray * Sf + f]));
-        }
-        __syncthreads();
-        // stratified_sampler.py:87-90  sort(cat[coarse, fine]) -- rank sort, S^2/64 compares
-        for (int e = lane; e < S; e += WAVE) {
-            const float x = t_raw[e];
-            int rank = 0;
-            for (int j = 0; j < S; ++j) {
-                const float xj = t_raw[j];
-                rank += (xj < x || (xj == x && j < e)) ? 1 : 0;
-            }
-            t_srt[rank] = x;
-        }
-        __syncthreads();
+        wave_fence();   // the previous ray's row has been written out
+        render::hierarchical_ray(lane, Sc, Sf, t_bins, ps, weights + ray * Sc, u1 + ray * Sc, u2 + ray * Sf,
+                                 u3 + ray * Sf, bin_idx ? bin_idx + ray * Sf : nullptr, scratch, t_srt);
         write_samples(t_srt, S, lane, ray, ray_o, ray_d, t_out, pts, dirs, delta);
     }
 }
@@ -209,7 +94,7 @@ NERF_API int nerf_sample_hierarchical(const float *ray_o, const float *ray_d, in
     NERF_REQUIRE(ray_o && ray_d && t_bins && weights && u1 && (Sf == 0 || (u2 && u3)) && pts && dirs &&
                      delta,
                  "nerf_sample_hierarchical: null pointer");
-    const size_t floats = (size_t)2 * (Sc + Sf) + 2 * (size_t)Sc + 16;
+    const size_t floats = (size_t)((Sc + Sf + 3) & ~3) + (size_t)render::hierarchical_scratch_floats(Sc, Sf);
     if (floats > (size_t)MAX_LDS_FLOATS)
         return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_sample_hierarchical: Sc+Sf too large for LDS");
     const unsigned grid = (unsigned)(n < 1048576 ? n : 1048576);

@@ -43,7 +43,10 @@ SIGNATURES = {
     "nerf_mlp_backward": (_c_int, [_p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_composite_forward": (_c_int, [_p, _p, _p, _c_i64, _c_int, _p, _p, _p]),
     "nerf_composite_backward": (_c_int, [_p, _p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p]),
+    "nerf_render_is_fused": (_c_int, [_c_int, _c_int, _c_int]),
     "nerf_render_workspace_bytes": (_c_i64, [_c_i64, _c_int]),
+    "nerf_render_pass": (_c_int, [_p, _p, _p, _c_i64, _c_int, _c_int, _p, _c_f, _p, _p, _p, _p, _p, _p, _p, _p,
+                                  _p, _p]),
     "nerf_render_rays": (_c_int, [_p, _p, _p, _c_i64, _c_int, _c_int, _p, _c_f, _p, _p, _p, _p, _p, _p,
                                   _p, _p]),
     "nerf_counter_uniform": (_c_int, [ctypes.c_uint64, _c_i64, _c_i64, _p, _p]),

@@ -162,8 +162,8 @@ def mlp_pack(flat_params: torch.Tensor) -> torch.Tensor:
 # When set to a list, every MLP launch appends (tag, M, start_event, end_event) recorded on the
 # launch stream: bench.py uses it to time the dominant kernel inside the timed region.
 KERNEL_EVENTS = None
-# what rocprofv3 calls the kernel behind the "mlp_forward" tag on the inference path (bench.py roofline object)
-DOMINANT_KERNEL = "mlp_forward_kernel<false,false> (fused posenc + 11-layer MLP)"
+# what rocprofv3 calls the kernel behind the "render_pass" tag on the inference path (bench.py roofline object)
+DOMINANT_KERNEL = "render_fused_kernel (sampling + posenc + 11-layer MLP + integral in one kernel)"
 DOMINANT_KERNEL_BF16 = "mlp_forward_bf16_kernel (fused posenc + 11-layer MLP on v_mfma_f32_32x32x16_bf16)"
 
 
@@ -363,9 +363,17 @@ class CompositeFunction(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- fused pass
-def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, u2=None, u3=None, bf16=False):
-    """One inference render_scene pass as a single enqueue -> (rgb (n,3), weights (n,S)).
-    bf16=True: `packed` is a mlp_pack_bf16 stream and the MLP runs on the bf16 MFMA path."""
+def render_is_fused(n_coarse: int, n_fine: int, fine: bool) -> bool:
+    """True if render_rays runs this pass as ONE kernel (csrc/render_fused.hip)."""
+    return bool(_lib.load().nerf_render_is_fused(int(n_coarse), int(n_fine), int(bool(fine))))
+
+
+def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, u2=None, u3=None, bf16=False,
+                want_idx=False, want_t=False):
+    """One inference render_scene pass as a single enqueue -> (rgb (n,3), weights (n,S)[, idx (n,Sf)][, t (n,S)]).
+    For the sample counts of the reference's configurations (64, 64+128) that is ONE kernel: sampling, the fused
+    encode + MLP and the integral, with no intermediate in HBM.  `weights` (fine pass) is floored in place.
+    bf16=True: `packed` is a mlp_pack_bf16 stream and the MLP runs on the bf16 MFMA path (three launches)."""
     if bf16:
         if weights is None:
             pts, dirs, delta = sample_stratified(ray_o, ray_d, t_bins, partition_size, u1)
@@ -379,15 +387,30 @@ def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, 
     n, Sc = u1.shape
     Sf = 0
     if weights is not None:
+        if not (weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()):
+            raise RuntimeError("weights must be a contiguous fp32 GPU tensor (it is updated in place)")
         u2, u3 = _gpu(u2, "u2"), _gpu(u3, "u3")
         Sf = u2.shape[1]
     S = Sc + Sf
     dev = u1.device
     rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
     w_out = torch.empty((n, S), dtype=torch.float32, device=dev)
-    ws = torch.empty((lib.nerf_render_workspace_bytes(n, S),), dtype=torch.uint8, device=dev)
+    idx = torch.empty((n, Sf), dtype=torch.int64, device=dev) if (want_idx and weights is not None) else None
+    t = torch.empty((n, S), dtype=torch.float32, device=dev) if want_t else None
+    ws = None
+    if not lib.nerf_render_is_fused(Sc, Sf, int(weights is not None)):
+        ws = torch.empty((lib.nerf_render_workspace_bytes(n, S),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.nerf_render_rays(_ptr(packed), _ptr(ray_o), _ptr(ray_d), n, Sc, Sf, _ptr(t_bins),
+        end = _timed("render_pass", n * S)
+        _lib.check(lib.nerf_render_pass(_ptr(packed), _ptr(ray_o), _ptr(ray_d), n, Sc, Sf, _ptr(t_bins),
                                         float(partition_size), _ptr(weights), _ptr(u1), _ptr(u2), _ptr(u3),
-                                        _ptr(rgb), _ptr(w_out), _ptr(ws), _stream()), "nerf_render_rays")
-    return rgb, w_out
+                                        _ptr(rgb), _ptr(w_out), _ptr(idx), _ptr(t), _ptr(ws), _stream()),
+                   "nerf_render_pass")
+        if end is not None:
+            end.record()
+    out = [rgb, w_out]
+    if want_idx:
+        out.append(idx)
+    if want_t:
+        out.append(t)
+    return tuple(out)

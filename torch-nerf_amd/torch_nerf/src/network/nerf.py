@@ -70,6 +70,13 @@ class NeRF(nn.Module):
             self._pack_key = key
         return params, self._flat, self._packed
 
+    def _stream_bf16(self):
+        """The bf16 fragment stream of the current parameters (BASELINE configs[2]), packed on first use."""
+        _, flat, _ = self._stream()
+        if self._packed_bf16 is None:
+            self._packed_bf16 = ops.mlp_pack_bf16(flat)
+        return self._packed_bf16
+
     @staticmethod
     def _blob_view(params):
         """The 22 tensors as ONE flat fp32 view if they already sit back to back in one storage, in
@@ -117,9 +124,7 @@ class NeRF(nn.Module):
         """points, view_dirs (M,3) RAW: positional encoding happens inside the kernel."""
         params, flat, packed = self._stream()
         if self.bf16_inference and not self._wants_grad(params):
-            if self._packed_bf16 is None:
-                self._packed_bf16 = ops.mlp_pack_bf16(flat)
-            return ops.mlp_forward_bf16(self._packed_bf16, points, view_dirs)
+            return ops.mlp_forward_bf16(self._stream_bf16(), points, view_dirs)
         return ops.NerfMLPFunction.apply(points, view_dirs, False, self._wants_grad(params), packed, flat, *params)
 
     pos_dim = property(lambda self: self._pos_dim)

@@ -28,38 +28,48 @@ class StratifiedSampler(RaySamplerBase):
         weights absent -> stratified:   num_samples = S
         """
         hierarchical = weights is not None
-        if hierarchical:
-            if not isinstance(weights, torch.Tensor):
-                raise ValueError(f"Expected an instance of torch.Tensor. Got {type(weights)}.")
-            if not isinstance(num_samples, (tuple, list)):
-                raise ValueError(
-                    "Expected a tuple for parameter 'num_samples' when hierarchical sampling is used. "
-                    f"Got a parameter of type {type(num_samples)}.")
-            n_coarse, n_fine = num_samples
-        else:
-            if not isinstance(num_samples, int):
-                raise ValueError(
-                    "Expected an integer for parameter 'num_samples' when hierarchical sampling is unused. "
-                    f"Got a parameter of type {type(num_samples)}.")
-            n_coarse, n_fine = num_samples, 0
-
+        n_coarse, n_fine = self.check_sample_counts(num_samples, weights)
         t_bins, partition_size = self._create_t_bins(ray_bundle.t_near, ray_bundle.t_far, n_coarse, device)
         dev = t_bins.device
         origin = ray_bundle.ray_origin.to(dev)
         direction = ray_bundle.ray_dir.to(dev)
-        n_rays = origin.shape[0]
-        u1 = torch.rand((n_rays, n_coarse), device=dev)                      # :77 / :109
+        u1, u2, u3 = self.draw_uniforms(origin.shape[0], n_coarse, n_fine, dev)
         if not hierarchical:
             return ops.sample_stratified(origin, direction, t_bins, partition_size, u1)
-
-        u2 = torch.rand((n_rays, n_fine), device=dev)                        # utils.py:43
-        u3 = torch.rand((n_rays, n_fine), device=dev)                        # utils.py:56
         w = weights.detach().to(dev)
         w_c = w if (w.is_contiguous() and w.dtype == torch.float32) else w.contiguous().float()
         out = ops.sample_hierarchical(origin, direction, t_bins, partition_size, w_c, u1, u2, u3)
         if w_c is not w:
             w.copy_(w_c)                                                     # keep the in-place side effect
         return out
+
+    @staticmethod
+    def check_sample_counts(num_samples, weights) -> Tuple[int, int]:
+        """(n_coarse, n_fine) after the reference's argument checks (stratified_sampler.py:58-64, :92-96);
+        n_fine = 0 for the stratified branch."""
+        if weights is not None:
+            if not isinstance(weights, torch.Tensor):
+                raise ValueError(f"Expected an instance of torch.Tensor. Got {type(weights)}.")
+            if not isinstance(num_samples, (tuple, list)):
+                raise ValueError(
+                    "Expected a tuple for parameter 'num_samples' when hierarchical sampling is used. "
+                    f"Got a parameter of type {type(num_samples)}.")
+            return int(num_samples[0]), int(num_samples[1])
+        if not isinstance(num_samples, int):
+            raise ValueError(
+                "Expected an integer for parameter 'num_samples' when hierarchical sampling is unused. "
+                f"Got a parameter of type {type(num_samples)}.")
+        return num_samples, 0
+
+    @staticmethod
+    def draw_uniforms(n_rays: int, n_coarse: int, n_fine: int, dev):
+        """The draws of one sample_along_rays call, with the reference's torch calls in its order and shapes:
+        U1 (N,Sc) coarse jitter (:77 / :109) [-> U2 (N,Sf) cdf ordinates (utils.py:43) -> U3 (N,Sf) in-bin jitter
+        (utils.py:56)]; a seed therefore reproduces the reference's stream on the same device."""
+        u1 = torch.rand((n_rays, n_coarse), device=dev)
+        if n_fine <= 0:
+            return u1, None, None
+        return u1, torch.rand((n_rays, n_fine), device=dev), torch.rand((n_rays, n_fine), device=dev)
 
     def _create_t_bins(self, t_start: float, t_end: float, num_partitions: int, device):
         """Left edges of `num_partitions` equal bins of [t_start, t_end) and the bin width."""

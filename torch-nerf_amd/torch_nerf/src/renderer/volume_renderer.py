@@ -8,8 +8,11 @@ constructor, `render_scene` signature / validation / return convention
 What changed underneath:
   * the (H*W, 2) screen-coordinate table is evaluated inside the ray-generation kernel
     from the flat pixel index; the CPU table is only materialised if `screen_coords` is read
-  * sampling, encoding+MLP and the integral are three HIP kernels per pass; the Python loop
-    over ray batches (:229-254) is gone -- activations live in registers, so there is
+  * inference with the stock parts (StratifiedSampler, QuadratureIntegrator, a PrimitiveCube over the HIP NeRF
+    with the two standard encoders) is ONE kernel per pass: sampling, encode + MLP and the integral
+    (csrc/render_fused.hip); sample points, directions, delta, sigma and radiance never reach HBM
+  * otherwise (training, foreign parts) sampling, encoding+MLP and the integral are three HIP kernels per pass
+  * the Python loop over ray batches (:229-254) is gone -- activations live in registers, so there is
     nothing to run out of memory on; `num_ray_batch` is accepted and ignored for scenes
     that expose the fused query, and honoured for any other `target_scene`
 """
@@ -73,11 +76,46 @@ class VolumeRenderer(object):
             coords = self.screen_coords.clone()[pixel_to_render, :]
             ray_bundle = self.sampler.generate_rays(coords, cam, project_to_ndc=project_to_ndc)
 
+        fused = self._render_fused(target_scene, ray_bundle, num_samples, device, weights)
+        if fused is not None:
+            return fused[0], pixel_to_render, fused[1]
         sample_pts, ray_dir, delta_t = self.sampler.sample_along_rays(ray_bundle, num_samples, device=device,
                                                                       weights=weights)
         pixel_rgb, weights, _, _ = self._render_ray_batches(
             target_scene, sample_pts, ray_dir, delta_t, num_batch=1 if num_ray_batch is None else num_ray_batch)
         return pixel_rgb, pixel_to_render, weights
+
+    def _render_fused(self, target_scene, ray_bundle, num_samples, device, weights):
+        """(pixel_rgb, weights) through the single-kernel pass, or None if this call is not eligible: gradients
+        wanted, or any part that is not the stock one (a subclass may override what the fused kernel hard-wires)."""
+        from torch_nerf.amd import ops
+        if type(self.sampler) is not ray_samplers.StratifiedSampler or \
+                type(self.integrator) is not integrators.QuadratureIntegrator or \
+                type(target_scene) is not scene.PrimitiveCube or not target_scene.fused_query:
+            return None
+        net = target_scene.radiance_field
+        params, flat, packed = net._stream()
+        if net._wants_grad(params):
+            return None
+        hierarchical = weights is not None
+        # the sampler's own argument checks (stratified_sampler.py:58-64, :92-96)
+        n_coarse, n_fine = self.sampler.check_sample_counts(num_samples, weights)
+        t_bins, partition_size = self.sampler._create_t_bins(ray_bundle.t_near, ray_bundle.t_far, n_coarse, device)
+        dev = t_bins.device
+        origin, direction = ray_bundle.ray_origin.to(dev), ray_bundle.ray_dir.to(dev)
+        u1, u2, u3 = self.sampler.draw_uniforms(origin.shape[0], n_coarse, n_fine if hierarchical else 0, dev)
+        bf16 = bool(getattr(net, "bf16_inference", False))
+        if bf16:
+            packed = net._stream_bf16()
+        if not hierarchical:
+            return ops.render_rays(packed, origin, direction, t_bins, partition_size, u1, bf16=bf16)
+        w = weights.detach().to(dev)
+        w_c = w if (w.is_contiguous() and w.dtype == torch.float32) else w.contiguous().float()
+        out = ops.render_rays(packed, origin, direction, t_bins, partition_size, u1, weights=w_c, u2=u2, u3=u3,
+                              bf16=bf16)
+        if w_c is not w:
+            w.copy_(w_c)                                                     # keep the in-place side effect
+        return out
 
     def _generate_screen_coords(self) -> torch.Tensor:
         """(H*W, 2) int64: column 0 = x, column 1 = H-1-row (rows flipped)."""
