@@ -251,15 +251,20 @@ def cpu_baseline(flats, focal, pose, device):
 
 def hbm_stages(device, reps=20):
     """the stages outside the MLP are HBM-bound and reported separately against 8 TB/s.
-    Each kernel at the full batch (4096 rays; 64 or 64+128 samples), HIP events on the launch stream around
-    every launch, median; bytes = the algorithmic traffic of the stage."""
-    from torch_nerf.amd import ops
+    Each kernel at the full batch (4096 rays; 64 or 64+128 samples) straight through the C ABI on preallocated
+    buffers: `reps` launches back to back behind a GPU-side sleep (so that the host is ahead and the events see
+    kernel time + launch boundary only), HIP events around the run; bytes = the algorithmic traffic of the
+    stage.  (Inference runs these stages inside the fused render kernel; training runs them
+    as kernels.)"""
+    import ctypes
+    from torch_nerf.amd import _lib
+    lib = _lib.load()
     n, Sc, Sf = RAYS, N_COARSE, N_FINE
     S = Sc + Sf
     g = torch.Generator(device=device).manual_seed(5)
     o = torch.randn((n, 3), device=device, generator=g)
     d = torch.randn((n, 3), device=device, generator=g)
-    t_bins = torch.linspace(NEAR, FAR, Sc + 1, device=device)[:-1]
+    t_bins = torch.linspace(NEAR, FAR, Sc + 1, device=device)[:-1].contiguous()
     ps = (FAR - NEAR) / Sc
     u1, u2, u3 = (torch.rand((n, k), device=device, generator=g) for k in (Sc, Sf, Sf))
     w = torch.rand((n, Sc), device=device, generator=g)
@@ -267,37 +272,47 @@ def hbm_stages(device, reps=20):
     rad = torch.rand((n, S, 3), device=device, generator=g)
     delta = torch.full((n, S), 4.0 / S, device=device)
     g_rgb = torch.randn((n, 3), device=device, generator=g)
+    pts, dirs = torch.empty((n, S, 3), device=device), torch.empty((n, S, 3), device=device)
+    dl, wo, gs = torch.empty((n, S), device=device), torch.empty((n, S), device=device), torch.empty((n, S), device=device)
+    rgb, gc = torch.empty((n, 3), device=device), torch.empty((n, S, 3), device=device)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     cases = {
-        "stratified": (lambda: ops.sample_stratified(o, d, t_bins, ps, u1), n * Sc * 32 + n * 24,
+        "stratified": (lambda: lib.nerf_sample_stratified(P(o), P(d), n, Sc, P(t_bins), ps, P(u1), None, P(pts), P(dirs),
+                                                          P(dl), st), n * Sc * 32 + n * 24,
                        "u1 4 B in; pts 12 + dirs 12 + delta 4 B out per sample; o, d per ray"),
-        "hierarchical": (lambda: ops.sample_hierarchical(o, d, t_bins, ps, w.clone(), u1, u2, u3),
+        "hierarchical": (lambda: lib.nerf_sample_hierarchical(P(o), P(d), n, Sc, Sf, P(t_bins), ps, P(w), P(u1), P(u2),
+                                                              P(u3), None, None, P(pts), P(dirs), P(dl), st),
                          n * (Sc * 12 + Sf * 8 + S * 28 + 24),
                          "weights 4 B read + 4 B written back, u1 4 B per coarse sample; u2, u3 4 B per fine sample; "
                          "pts 12 + dirs 12 + delta 4 B out per sorted sample; o, d per ray"),
-        "composite_fwd": (lambda: ops.composite_forward(sigma, rad, delta), n * S * 24 + n * 12,
+        "composite_fwd": (lambda: lib.nerf_composite_forward(P(sigma), P(rad), P(delta), n, S, P(rgb), P(wo), st),
+                          n * S * 24 + n * 12,
                           "sigma 4 + radiance 12 + delta 4 B in, weights 4 B out per sample; rgb 12 B per ray"),
-        "composite_bwd": (lambda: ops.composite_backward(sigma, rad, delta, g_rgb), n * S * 36 + n * 12,
+        "composite_bwd": (lambda: lib.nerf_composite_backward(P(sigma), P(rad), P(delta), P(g_rgb), None, n, S, P(gs),
+                                                              P(gc), st), n * S * 36 + n * 12,
                           "sigma 4 + radiance 12 + delta 4 B in, g_sigma 4 + g_radiance 12 B out per sample; "
                           "g_rgb 12 B per ray"),
     }
     out = {}
     for name, (fn, nbytes, what) in cases.items():
         for _ in range(3):
-            fn()
-        ms = []
-        for _ in range(reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn()
-            e1.record()
-            ms.append((e0, e1))
+            assert fn() == 0, name
         torch.cuda.synchronize()
-        t = float(np.median([a.elapsed_time(b) for a, b in ms]))     # includes the torch.empty of the outputs
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(4_000_000)          # ~2 ms of GPU time: the launches below queue up behind it
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / reps
         gbs = nbytes / (t * 1e-3) / 1e9
         out[name] = {"us": round(t * 1e3, 2), "bytes": nbytes, "achieved_GBs": round(gbs, 1),
                      "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "traffic": what}
-    out["note"] = (f"{n} rays x {Sc} (stratified) / {Sc}+{Sf} (others) samples; a stage of 5-40 us is launch- and "
-                   "latency-bound at this batch size, so the fraction is a lower bound on the kernel's streaming rate")
+    out["note"] = (f"{n} rays x {Sc} (stratified) / {Sc}+{Sf} (others) samples, mean of {reps} back-to-back launches "
+                   "(kernel + launch boundary); one-wave-per-ray kernels of 5-45 us are latency-bound at this batch "
+                   "size, so the fraction is a lower bound on their streaming rate")
     return out
 
 
@@ -466,7 +481,7 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("mlp_forward_hbm_bytes_per_launch")
+        traffic = json.load(open(tpath)).get("dominant_kernel_hbm_bytes_per_launch")
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "kernel": ops.DOMINANT_KERNEL + ", 2 launches/step",

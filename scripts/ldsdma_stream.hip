@@ -167,16 +167,22 @@ int main() {
     hipMemcpy(image, host.data(), host.size() * 2, hipMemcpyHostToDevice);
     printf("%s, %d CUs; every CU streams the same %.2f MB image\n", prop.name, cus, IMAGE_BYTES / 1e6);
 #define RUN(W, S, N, M, C, D, SP, CH) run<W, S, N, M, C, D, SP, CH>(image, out, clk, cus);
-    RUN(8, 32768, 4, 3, 1, 4, 0, 1)
-    RUN(8, 32768, 4, 3, 1, 4, 0, 2)
-    RUN(8, 32768, 4, 3, 1, 4, 0, 4)
+    RUN(8, 32768, 4, 3, 1, 4, 0, 1)   // warm-up (discard)
+    // bare MFMAs, + ds_read_b128 A fragments, + the 64 KiB / 256 samples weight stream: 8 waves x 1 column block ...
     RUN(8, 32768, 4, 3, 1, 4, 0, 1)
     RUN(8, 32768, 4, 2, 1, 4, 0, 1)
-    RUN(8, 32768, 4, 2, 1, 4, 0, 4)
+    RUN(8, 32768, 4, 1, 1, 4, 0, 1)
     RUN(8, 32768, 4, 1, 1, 4, 1, 1)
-    RUN(8, 32768, 4, 1, 1, 4, 1, 4)
-    RUN(8, 32768, 4, 1, 1, 4, 1, 1)
+    RUN(8, 65536, 2, 1, 1, 4, 1, 1)
+    // ... and 4 waves x 2 column blocks (one A fragment feeds two MFMAs)
+    RUN(4, 32768, 4, 3, 2, 4, 0, 1)
+    RUN(4, 32768, 4, 2, 2, 4, 0, 1)
+    RUN(4, 32768, 4, 1, 2, 4, 0, 1)
     RUN(4, 32768, 4, 1, 2, 4, 1, 1)
-    RUN(4, 32768, 4, 1, 2, 4, 1, 2)
+    // the round-1 geometry: 4 waves x 1 column block (64 KiB per 128 samples)
+    RUN(4, 65536, 2, 1, 1, 4, 1, 1)
+    // the stream alone
+    RUN(8, 32768, 4, 0, 1, 4, 0, 1)
+    RUN(4, 65536, 2, 0, 1, 4, 0, 1)
     return 0;
 }
