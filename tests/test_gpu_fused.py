@@ -85,7 +85,7 @@ def test_fused_pass_against_golden_f7_and_f3_bins(golden):
         if not ops.render_is_fused(Sc, Sf, True):
             continue
         out = ops.render_rays(pf, dev(g3[case + "_o"]), dev(g3[case + "_d"]), dev(g3[case + "_t_bins"]),
-                              float(g3[case + "_ps"]), dev(g3[case + "_u1"]), weights=w, u2=dev(g3[case + "_u2"]),
+                              float(g3[case + "_ps"][0]), dev(g3[case + "_u1"]), weights=w, u2=dev(g3[case + "_u2"]),
                               u3=dev(g3[case + "_u3"]), want_idx=True, want_t=True)
         assert np.array_equal(out[2].cpu().numpy(), g3[case + "_idx"]), case
         assert np.array_equal(out[3].cpu().numpy().view(np.uint32), g3[case + "_t"].view(np.uint32)), case

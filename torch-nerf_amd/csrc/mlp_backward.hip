@@ -189,9 +189,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 // stage 2: dW GEMMs
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_GEMMS = 13;
-constexpr int SLICE_EXTRA = 256;  // floats reserved after each partial tile: the bias partial
-constexpr int DW_LDS_BYTES = 131072;  // 2 stages of 64 KiB (wide X) or 3 stages of 40 KiB (thin X)
-enum { FLAG_BIAS = 1 };
+constexpr int SLICE_EXTRA = 768;  // floats reserved after each partial tile: bias partial [256], density row [256], sum of dsig [1]
+constexpr int DW_LDS_BYTES = 131072 + 256;  // 2 stages of 64 KiB (wide X) or 3 stages of 40 KiB (thin X), + two dsig rows
+enum { FLAG_BIAS = 1, FLAG_DENSITY = 2 };   // FLAG_DENSITY: the fc_8 item also sums the density row (below)
 
 struct GemmDesc {
     int64_t a_off;        // dY plane, float offset into the dy workspace
@@ -201,7 +201,9 @@ struct GemmDesc {
     int64_t b_off;        // destination: bias offset (row0 already applied by the reducer)
     int a_width;          // 256 | 128  (output features of the layer = rows of dW)
     int x_width;          // 256 | 64 | 32 (padded input features of this column block)
-    int first_block, num_slices;
+    int first_block, num_slices;  // the workgroups [first_block, first_block + num_slices) hold tiles of this item
+    int cost;                     // relative time of one 32-row tile of this item (work units)
+    int64_t unit_off;             // work units of all earlier items: tile j of this item starts at unit_off + j * cost
     int flags;
     int in_features;      // row stride of the destination weight tensor
     int col0, valid_cols; // destination column block
@@ -210,6 +212,7 @@ struct GemmDesc {
 struct GemmTable {
     GemmDesc g[MAX_GEMMS];
     int n;
+    int64_t work_total;           // sum over items of tiles * cost
 };
 
 __device__ __forceinline__ int64_t slice_stride(const GemmDesc &g) {
@@ -231,10 +234,21 @@ __device__ __forceinline__ void wait_vmcnt() {
     if (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
 }
 
-template <int NA, int KB>
-__device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const float *__restrict__ saved,
-                                        const float *__restrict__ dy, float *__restrict__ partial, int64_t MP,
-                                        char *lds, int tid, int lane, int wave) {
+// DENSITY (the fc_8 item, X = h7): the density row of fc_8 rides along on the vector ALU --
+//   dW8[0][k] = sum_m dsig[m] h7[m][k],  db8[0] = sum_m dsig[m]   (nerf.py:113-115: sigma = relu(fc_8(x)[:, 0]))
+// -- with the X fragments this GEMM holds in registers anyway.  Vector instructions between the MFMAs of a wave are
+// NOT free on this machine (measured: ~7 cycles each next to 64-cycle fp32 MFMAs), so the job is kept to two FMAs
+// and one LDS read per k-step: wave w takes feature blocks 2w, 2w+1 (the body is compiled once per wave: a run-time
+// choice of fragments becomes branches in the k-loop), and dsig reaches the lanes through a 128-byte LDS row that
+// wave 0 fills one tile ahead from a HAND-ISSUED load (a compiler-visible load makes hipcc insert vmcnt waits
+// that also wait for the tile DMA: 16.8 instead of 8.8 ms; scalar loads at the point of use stall every k-step).
+// The sum of dsig itself (db8[0]) is left to the thin vector kernel, which reads 4 B/sample for it.  (Round 1 summed
+// the row in a separate HBM-bound kernel that read the whole h7 plane, 1 KB/sample, a second time: 0.2 ms per step.)
+template <int NA, int KB, int DWAVE = -1>   // DWAVE >= 0: the density side job, compiled for wave DWAVE
+__device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0, int64_t t1,
+                                        const float *__restrict__ saved, const float *__restrict__ dy,
+                                        float *__restrict__ partial, int64_t MP, char *lds, int tid, int lane,
+                                        int wave) {
     constexpr int AW = 128 * NA;  // a_width: each of the 4 waves owns 32*NA rows
     constexpr int XW = 32 * KB;
     constexpr int A_PIECES = 32 * AW * 4 / 1024 / 4;  // 1-KiB DMA pieces per wave
@@ -249,11 +263,7 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
     const int i = lane & 31, h = lane >> 5;
     const int frag_base = (i >> 3) * 256 + 4 * ((2 * h + ((i >> 2) & 1)) ^ (2 * ((i >> 3) & 1))) + (i & 3);
     const int frag_swing = 16 * (i >> 4);
-    const int64_t tiles_total = MP / 32;
-    const int num_slices = g.num_slices;
-    const bool want_bias = (g.flags & FLAG_BIAS) != 0;
-    const int64_t t0 = tiles_total * slice / num_slices;
-    const int64_t t1 = tiles_total * (slice + 1) / num_slices;
+    const bool want_bias = (g.flags & FLAG_BIAS) != 0;   // tiles [t0, t1) of the item; an empty range writes a zero partial
     const char *a_src = reinterpret_cast<const char *>(dy + g.a_off);      // wave-uniform; the lane offset rides
     const char *x_src = reinterpret_cast<const char *>(saved + g.x_off);   // in the DMA instruction's vector operand
     const unsigned lane_off = (unsigned)lane * 16u;
@@ -270,6 +280,21 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
     float bsum[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) bsum[a] = 0.0f;
+    constexpr bool DENSITY = DWAVE >= 0;
+    static_assert(!DENSITY || (KB == 8 && NSTAGE == 2), "the density side job belongs to the 256-wide fc_8 item");
+    static_assert(NSTAGE * STAGE_BYTES + 256 <= DW_LDS_BYTES || !DENSITY, "no room for the dsig rows");
+    float drow[2] = {0.0f, 0.0f};
+    const float *dsig = dy + dsig_plane(MP);
+    // two 128-byte LDS rows behind the stages: row (t & 1) holds dsig of tile t
+    const unsigned ds_rows = lds_base + NSTAGE * STAGE_BYTES;
+    float ds_pend = 0.0f;   // wave 0: dsig[tile * 32 + i] of the tile AFTER the next one being staged
+    if (DENSITY && DWAVE == 0 && t0 < t1) {
+        // tile t0 goes straight into its row (visible after the first tile-top barrier), tile t0 + 1 is requested
+        float first;
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(first) : "v"(dsig + t0 * 32 + i) : "memory");
+        if (h == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(ds_rows + (unsigned)(t0 & 1) * 128u + 4u * i), "v"(first) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(ds_pend) : "v"(dsig + (t0 + 1 < t1 ? t0 + 1 : t1 - 1) * 32 + i) : "memory");
+    }
 
     // piece j (0 .. PER_WAVE-1) of tile t into stage `buf`: A pieces first, then X pieces
     auto issue_piece = [&](int64_t t, int buf, int j) {
@@ -288,7 +313,8 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
 
     // prologue: NSTAGE-1 tiles in flight (tiles past the end are re-reads of the last tile: the
     // instruction count per step stays fixed so the counted wait below is exact)
-    for (int d = 0; d < NSTAGE - 1; ++d) issue(t0 + d < t1 ? t0 + d : t1 - 1, d);
+    if (t0 < t1)
+        for (int d = 0; d < NSTAGE - 1; ++d) issue(t0 + d < t1 ? t0 + d : t1 - 1, d);
     int buf = 0;
     for (int64_t t = t0; t < t1; ++t) {
         wait_vmcnt<(NSTAGE - 2) * PER_WAVE>();   // tile t landed (this wave's pieces) ...
@@ -311,13 +337,22 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
                                     stage + 4u * (unsigned)(wave * NA * 1024 + frag_base - frag_swing)};
         const unsigned x_addr[2] = {stage + (unsigned)A_BYTES + 4u * (unsigned)(frag_base + frag_swing),
                                     stage + (unsigned)A_BYTES + 4u * (unsigned)(frag_base - frag_swing)};
-        float a[2][NA], b[2][KB];
+        if (DENSITY && DWAVE == 0) {
+            // behind the tile-top vmcnt(0) the values of tile t + 1 have landed: into the row nobody reads during
+            // tile t (readers of row (t+1)&1 = row (t-1)&1 passed this tile's barrier); then request tile t + 2
+            if (h == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(ds_rows + (unsigned)((t + 1) & 1) * 128u + 4u * i), "v"(ds_pend) : "memory");
+            const int64_t t2 = t + 2 < t1 ? t + 2 : t1 - 1;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(ds_pend) : "v"(dsig + t2 * 32 + i) : "memory");
+        }
+        const unsigned ds_addr = ds_rows + (unsigned)(t & 1) * 128u + 4u * (unsigned)h;
+        float a[2][NA], b[2][KB], dval[2] = {0.0f, 0.0f};
 #define DW_FETCH(S)                                                                                   \
         {                                                                                             \
             _Pragma("unroll") for (int nb = 0; nb < NA; ++nb)                                         \
                 a[(S) & 1][nb] = lds_read_b32(a_addr[(S) & 1], nb * 4096 + 64 * (S));                 \
             _Pragma("unroll") for (int kb = 0; kb < KB; ++kb)                                         \
                 b[(S) & 1][kb] = lds_read_b32(x_addr[(S) & 1], kb * 4096 + 64 * (S));                 \
+            if (DENSITY) dval[(S) & 1] = lds_read_b32(ds_addr, 8 * (S));   /* dsig of sample 2 S + h */  \
         }
         DW_FETCH(0)
         // dW += dY^T X over the 32 samples of the tile: 16 k-steps of 2 samples.  The A fragments
@@ -333,6 +368,15 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
                     acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][nb], b[s & 1][kb], acc[nb][kb], 0, 0, 0);
+            }
+            if (DENSITY) {   // this lane's k-step sample is 2 s + h
+                // asm volatile: a plain fmaf is free to sink below the NEXT step's hand-issued fragment reads, whose
+                // destination registers the compiler believes valid from the moment of issue (hipcc did exactly
+                // that -- all 16 FMAs at the end of the tile, reading fragments in flight; scripts/audit_asm_loads.py
+                // caught it)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(drow[j]) : "v"(dval[s & 1]), "v"(b[s & 1][2 * (DENSITY ? DWAVE : 0) + j]));
             }
         }
 #undef DW_FETCH
@@ -353,6 +397,13 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, const floa
         const float both = bsum[nb] + __shfl_xor(bsum[nb], 32, WAVE);  // even + odd samples
         if (want_bias && h == 0) out[AW * XW + wave * 32 * NA + 32 * nb + i] = both;
     }
+    if (DENSITY) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float both = drow[j] + __shfl_xor(drow[j], 32, WAVE);
+            if (h == 0) out[AW * XW + 256 + 32 * (2 * (DENSITY ? DWAVE : 0) + j) + i] = both;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, const float *__restrict__ saved,
@@ -365,27 +416,50 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, con
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t MP = padded_rows(M);
-    int gi = 0;
-    for (int k = 1; k < table.n; ++k)
-        if ((int)blockIdx.x >= table.g[k].first_block) gi = k;
-    const GemmDesc &g = table.g[gi];
-    const int slice = (int)blockIdx.x - g.first_block;
-    if (slice >= g.num_slices) return;
-    if (g.a_width == 256 && g.x_width == 256) dw_body<2, 8>(g, slice, saved, dy, partial, MP, lds, tid, lane, wave);
-    else if (g.a_width == 256 && g.x_width == 64) dw_body<2, 2>(g, slice, saved, dy, partial, MP, lds, tid, lane, wave);
-    else if (g.a_width == 128 && g.x_width == 256) dw_body<1, 8>(g, slice, saved, dy, partial, MP, lds, tid, lane, wave);
-    else dw_body<1, 1>(g, slice, saved, dy, partial, MP, lds, tid, lane, wave);
+    // Workgroup b owns the work interval [W b / B, W (b+1) / B) of the concatenated items (W = sum of tiles x cost):
+    // every tile whose start lies in it.  Most workgroups sit inside one item; the ~n workgroups on an item
+    // boundary finish one item's tail, flush its partial tile, and go on with the next item's head -- so all B
+    // workgroups end within a tile of each other, whatever the items' costs (round 1 gave every item a whole number
+    // of equal slices: 251 of 256 CUs busy and 5 % between the first and the last workgroup to finish).
+    const int64_t tiles = MP / 32;
+    const int64_t B = gridDim.x, b = blockIdx.x;
+    const int64_t lo = table.work_total * b / B, hi = table.work_total * (b + 1) / B;
+    bool first = true;
+    for (int k = 0; k < table.n; ++k) {
+        const GemmDesc &g = table.g[k];
+        const int slice = (int)b - g.first_block;
+        if (slice < 0 || slice >= g.num_slices) continue;
+        auto tile_at = [&](int64_t unit) {   // first tile of the item that starts at or after `unit`
+            const int64_t rel = unit - g.unit_off;
+            const int64_t j = rel <= 0 ? 0 : (rel + g.cost - 1) / g.cost;
+            return j < tiles ? j : tiles;
+        };
+        const int64_t t0 = tile_at(lo), t1 = tile_at(hi);
+        if (!first) {   // the previous item's last DMA pieces may still be landing in the stages
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        first = false;
+        if (g.flags & FLAG_DENSITY) {
+            if (wave == 0) dw_body<2, 8, 0>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+            else if (wave == 1) dw_body<2, 8, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+            else if (wave == 2) dw_body<2, 8, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+            else dw_body<2, 8, 3>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        } else if (g.a_width == 256 && g.x_width == 256) dw_body<2, 8>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_width == 256 && g.x_width == 64) dw_body<2, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_width == 128 && g.x_width == 256) dw_body<1, 8>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else dw_body<1, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (block_clocks && tid == 0) block_clocks[blockIdx.x] = wall_clock64() - clk0;  // 100 MHz ticks
 }
 
-// Thin outer-product sums on the vector ALU (an MFMA row block would be 3/32 resp. 1/32 used):
-//   job 0: fc_out   dW[c][k] = sum_m gy10[m][c] h9[m][k]  (3 x 128), db[c] = sum_m gy10[m][c]
-//   job 1: fc_8 row 0 (density)   dW[0][k] = sum_m dsig[m] h7[m][k]  (256), db[0] = sum_m dsig[m]
-// Block b of a job sums samples [b*chunk, (b+1)*chunk) with 8 rows in flight per thread group;
-// HBM-bound: reads the h9 (512 B/sample) resp. h7 (1 KB/sample) plane once.
+// Thin outer-product sum on the vector ALU (an MFMA row block would be 3/32 used):
+//   fc_out   dW[c][k] = sum_m gy10[m][c] h9[m][k]  (3 x 128), db[c] = sum_m gy10[m][c]
+// Block b sums samples [b*chunk, (b+1)*chunk) with 8 rows in flight per thread group; HBM-bound: reads the h9
+// plane (512 B/sample) once.  (The other thin product, the density row of fc_8, rides on the fc_8 GEMM: dw_body.)
 constexpr int VEC_BLOCKS = 1024;   // per job
-constexpr int VEC_STRIDE = 512;    // floats per block partial: job 0 uses 387, job 1 uses 257
+constexpr int VEC_STRIDE = 512;    // floats per block partial: 388 used
 __global__ __launch_bounds__(256) void mlp_bwd_vec_kernel(const float *__restrict__ saved,
                                                           const float *__restrict__ dy,
                                                           const float *__restrict__ rgb,
@@ -398,33 +472,19 @@ __global__ __launch_bounds__(256) void mlp_bwd_vec_kernel(const float *__restric
     const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
     float *out = partial_vec + ((int64_t)job * VEC_BLOCKS + blockIdx.x) * VEC_STRIDE;
     constexpr int U = 8;
-    if (job == 1) {
-        const float *h7 = saved + pl_h(MP, 7);
-        const float *dsig = dy + dsig_plane(MP);
-        const int k = threadIdx.x;
-        float w = 0.f, b = 0.f;
-        int64_t m = lo;
-        for (; m + U <= hi; m += U) {
-            float x[U], d[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { x[u] = h7[tf_offset(FEAT, m + u, k)]; d[u] = dsig[m + u]; }
-#pragma unroll
-            for (int u = 0; u < U; ++u) { w = fmaf(d[u], x[u], w); b += d[u]; }
-        }
-        for (; m < hi; ++m) { const float d = dsig[m]; w = fmaf(d, h7[tf_offset(FEAT, m, k)], w); b += d; }
-        out[k] = w;
-        if (k == 0) out[FEAT] = b;
-        return;
-    }
     const float *h9 = saved + pl_h9(MP);
     const int k = threadIdx.x & (HALF - 1), grp = threadIdx.x >> 7;
     float w[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
+    // db8[0] = sum_m dsig[m] (the density row's bias, nerf.py:113-115): threads k = 1 of both groups sum it on the side
+    const float *dsig = dy + dsig_plane(MP);
+    float dsum = 0.0f;
     int64_t m = lo + grp;
     for (; m + 2 * (U - 1) < hi; m += 2 * U) {
-        float x[U], gy[U][3];
+        float x[U], gy[U][3], dsv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t mm = m + 2 * u;
+            dsv[u] = (k == 1) ? dsig[mm] : 0.0f;
             x[u] = h9[tf_offset(HALF, mm, k)];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -433,11 +493,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_vec_kernel(const float *__restric
             }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+            dsum += dsv[u];
 #pragma unroll
             for (int c = 0; c < 3; ++c) { w[c] = fmaf(gy[u][c], x[u], w[c]); b[c] += gy[u][c]; }
+        }
     }
     for (; m < hi; m += 2) {
+        if (k == 1) dsum += dsig[m];
         const float x = h9[tf_offset(HALF, m, k)];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -452,8 +515,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_vec_kernel(const float *__restric
         red[grp][c * HALF + k] = w[c];
         if (k == 0) red[grp][3 * HALF + c] = b[c];
     }
+    if (k == 1) red[grp][3 * HALF + 3] = dsum;
     __syncthreads();
-    for (int e = threadIdx.x; e < 3 * HALF + 3; e += 256) out[e] = red[0][e] + red[1][e];
+    for (int e = threadIdx.x; e < 3 * HALF + 4; e += 256) out[e] = red[0][e] + red[1][e];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -464,10 +528,10 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
     const int gi = blockIdx.y;
     const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    if (gi >= table.n) {  // the two vector jobs
-        const int job = gi - table.n;
-        const int count = job == 0 ? 3 * HALF + 3 : FEAT + 1;
-        const float *src = partial_vec + (int64_t)job * VEC_BLOCKS * VEC_STRIDE;
+    if (gi >= table.n) {  // the vector job (fc_out)
+        const int job = 0;
+        const int count = 3 * HALF + 4;
+        const float *src = partial_vec;
         for (int64_t e = e0; e < count; e += step) {
             float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
             for (int b = 0; b < VEC_BLOCKS; b += 4) {
@@ -477,8 +541,9 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
                 s3 += src[(int64_t)(b + 3) * VEC_STRIDE + e];
             }
             const float s = (s0 + s1) + (s2 + s3);
-            if (job == 0) g_params[w_offset(10) + e] = s;  // fc_out weight (3,128) then bias (3): contiguous
-            else g_params[e < FEAT ? w_offset(8) + e : b_offset(8)] = s;  // fc_8.weight[0, :], fc_8.bias[0]
+            (void)job;
+            if (e < 3 * HALF + 3) g_params[w_offset(10) + e] = s;  // fc_out weight (3,128) then bias (3): contiguous
+            else g_params[b_offset(8)] = s;                        // fc_8.bias[0]: sum of dsig
         }
         return;
     }
@@ -486,17 +551,22 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
     const float *base = partial + g.partial_off;
     const int64_t stride = slice_stride(g);
     const int64_t tile = (int64_t)g.a_width * g.valid_cols;
-    const int64_t total = tile + ((g.flags & FLAG_BIAS) ? g.a_width : 0);
+    const int64_t with_bias = tile + ((g.flags & FLAG_BIAS) ? g.a_width : 0);
+    const int64_t total = with_bias + ((g.flags & FLAG_DENSITY) ? FEAT : 0);
     for (int64_t e = e0; e < total; e += step) {
         int64_t src, dst;
         if (e < tile) {
             const int n = (int)(e / g.valid_cols), k = (int)(e % g.valid_cols);
             src = (int64_t)n * g.x_width + k;
             dst = g.w_off + (int64_t)(n + g.row0) * g.in_features + g.col0 + k;
-        } else {
+        } else if (e < with_bias) {
             const int n = (int)(e - tile);
             src = (int64_t)g.a_width * g.x_width + n;
             dst = g.b_off + g.row0 + n;
+        } else {   // density row of fc_8: weight[0, :]
+            const int k = (int)(e - with_bias);
+            src = (int64_t)g.a_width * g.x_width + 256 + k;
+            dst = g.w_off + k;
         }
         float s = 0.0f;
         for (int sl = 0; sl < g.num_slices; ++sl) s += base[sl * stride + src];
@@ -532,30 +602,39 @@ Plan make_plan(int64_t M, int cus) {
     add(5, dy_plane(MP, 5), 256, pl_h(MP, 4), 256, E_POS, 256, 0, FLAG_BIAS);
     add(6, dy_plane(MP, 6), 256, pl_h(MP, 5), 256, 0, 256, 0, FLAG_BIAS);
     add(7, dy_plane(MP, 7), 256, pl_h(MP, 6), 256, 0, 256, 0, FLAG_BIAS);
-    add(8, dy_plane(MP, 8), 256, pl_h(MP, 7), 256, 0, 256, 1, FLAG_BIAS);
+    add(8, dy_plane(MP, 8), 256, pl_h(MP, 7), 256, 0, 256, 1, FLAG_BIAS | FLAG_DENSITY);
     add(9, dy9_plane(MP), 128, pl_y8(MP), 256, 0, 256, 0, FLAG_BIAS);
     add(9, dy9_plane(MP), 128, pl_de(MP), 32, FEAT, E_DIR, 0, 0);
     T.n = n;
-    // Slices proportional to the time one 32-row tile costs a workgroup (measured on MI355X, us):
-    // wide tiles are MFMA-bound (256 MFMAs/wave), thin ones are bound by the LDS-DMA round trip.
-    double cost[MAX_GEMMS], cost_sum = 0;
+    // Relative time of one 32-row tile per item shape (measured on MI355X with all CUs busy, ns; scripts/dw_timing.py):
+    // wide tiles are MFMA-bound (256 MFMAs per wave, 6.83 us at the peak), the thin ones lean on the DMA round trip.
+    // The fc_8 item carries the density row (+1.4 %).
+    int64_t units = 0;
     for (int k = 0; k < n; ++k) {
         const int aw = T.g[k].a_width, xw = T.g[k].x_width;
-        cost[k] = (aw == 256 && xw == 256) ? 7.6 : (aw == 256 && xw == 64) ? 2.5 : (aw == 128 && xw == 256) ? 4.4 : 1.3;
-        cost_sum += cost[k];
+        T.g[k].cost = (T.g[k].flags & FLAG_DENSITY) ? 7450 : (aw == 256 && xw == 256) ? 7350 : (aw == 256 && xw == 64) ? 2010
+                    : (aw == 128 && xw == 256) ? 3770 : 935;
+        T.g[k].unit_off = units;
+        units += tiles * T.g[k].cost;
     }
-    int block = 0;
+    T.work_total = units;
+    const int64_t B = tiles * n < cus ? tiles * n : cus;      // tiny batches: at most one workgroup per tile
+    auto owner = [&](int64_t unit) {                           // workgroup whose interval [W b / B, W (b+1) / B) holds `unit`
+        int64_t b = unit * B / units;
+        while (b + 1 < B && units * (b + 1) / B <= unit) ++b;
+        while (b > 0 && units * b / B > unit) --b;
+        return (int)b;
+    };
     int64_t off = 0;
     for (int k = 0; k < n; ++k) {
-        int64_t s = (int64_t)(cus * cost[k] / cost_sum);
-        if (s < 1) s = 1;
-        if (s > tiles) s = tiles;
-        T.g[k].first_block = block;
-        T.g[k].num_slices = (int)s;
+        const int fb = owner(T.g[k].unit_off);
+        const int lb = owner(T.g[k].unit_off + (tiles - 1) * T.g[k].cost);
+        T.g[k].first_block = fb;
+        T.g[k].num_slices = lb - fb + 1;
         T.g[k].partial_off = off;
-        block += (int)s;
-        off += s * ((int64_t)T.g[k].a_width * T.g[k].x_width + SLICE_EXTRA);
+        off += (int64_t)T.g[k].num_slices * ((int64_t)T.g[k].a_width * T.g[k].x_width + SLICE_EXTRA);
     }
+    const int block = (int)B;
     p.total_blocks = block;
     p.partial_floats = off;
     return p;
@@ -622,19 +701,21 @@ NERF_API int nerf_mlp_backward(const void *packed, const float *params, const fl
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(host.data(), clocks, sizeof(unsigned long long) * plan.total_blocks, hipMemcpyDeviceToHost);
         (void)hipFree(clocks);
-        if (FILE *f = fopen(timing_path, "w")) {
-            for (int k = 0; k < plan.table.n; ++k)
-                for (int sl = 0; sl < plan.table.g[k].num_slices; ++sl)
-                    fprintf(f, "%d %d %d %d %llu\n", k, plan.table.g[k].a_width, plan.table.g[k].x_width, sl,
-                            host[plan.table.g[k].first_block + sl]);
+        if (FILE *f = fopen(timing_path, "w")) {   // one line per workgroup: first item it works on, clocks (100 MHz)
+            for (int b = 0; b < plan.total_blocks; ++b) {
+                int item = 0;
+                for (int k = 0; k < plan.table.n; ++k)
+                    if (b >= plan.table.g[k].first_block && b < plan.table.g[k].first_block + plan.table.g[k].num_slices) { item = k; break; }
+                fprintf(f, "%d %d %d %d %llu\n", item, plan.table.g[item].a_width, plan.table.g[item].x_width, b, host[b]);
+            }
             fclose(f);
         }
     }
-    hipLaunchKernelGGL(mlp_bwd_vec_kernel, dim3(VEC_BLOCKS, 2), dim3(256), 0, s, sv, static_cast<const float *>(dy), rgb,
+    hipLaunchKernelGGL(mlp_bwd_vec_kernel, dim3(VEC_BLOCKS, 1), dim3(256), 0, s, sv, static_cast<const float *>(dy), rgb,
                        g_rgb, M, partial_vec);
     rc = nerf::check_launch("nerf_mlp_backward: vector sums");
     if (rc != NERF_OK) return rc;
-    hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(64, plan.table.n + 2), dim3(256), 0, s, plan.table,
+    hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(64, plan.table.n + 1), dim3(256), 0, s, plan.table,
                        static_cast<const float *>(partial), static_cast<const float *>(partial_vec), g_params);
     return nerf::check_launch("nerf_mlp_backward: reduce");
 }

@@ -263,20 +263,27 @@ template <int NFB>
 __device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, int h, const f32x16 *blk) {
     const int i = (int)(m & 31);
     const uint64_t tile_addr = reinterpret_cast<uint64_t>(plane + (m - i) * width);
-    // (address space 1 = global: rebuilt from integers the pointer would otherwise be generic, and a flat store
-    // also counts in lgkmcnt, i.e. the LDS fragment waits of the following MFMA pair would wait for it)
-    typedef __attribute__((address_space(1))) char global_char;
-    global_char *tile = reinterpret_cast<global_char *>(
-        ((uint64_t)__builtin_amdgcn_readfirstlane((int)(tile_addr >> 32)) << 32) |
-        (unsigned)__builtin_amdgcn_readfirstlane((int)tile_addr));
-    const unsigned unit = (unsigned)(2 * i + h);
+    // The tile address is wave-uniform: it goes into an SGPR pair and every store is
+    //     global_store_dwordx4 v_lane_offset, v[data], s[base:base+1] offset:q*1024
+    // with the feature block stepping the scalar base (SALU) and ONE lane register, (2 i + h) << 4, XORed with
+    // 32 q per slot.  Left to hipcc the stores take a 64-bit vector address each: the four lane offsets end up parked
+    // in AGPRs and every store costs two v_accvgpr_read + a 64-bit add, in a seam where every vector instruction is
+    // exposed.
+    const uint64_t tile = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(tile_addr >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)tile_addr);
+    const unsigned unit16 = (unsigned)(2 * i + h) << 4;
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb)
+    for (int fb = 0; fb < NFB; ++fb) {
+        const uint64_t base = tile + (uint64_t)fb * 4096u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
-            *reinterpret_cast<__attribute__((address_space(1))) f32x4 *>(tile + (4 * fb + q) * 1024 + ((unit ^ (2u * q)) << 4)) = v;
+            const f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3"
+                         :
+                         : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024)
+                         : "memory");
         }
+    }
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
