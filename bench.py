@@ -129,23 +129,42 @@ def train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank, steps, 
             dist.barrier()
             torch.cuda.synchronize()
 
+    from torch_nerf.amd import ops
     for s in range(warmup):
         step(s)
     fence()
+    ops.KERNEL_EVENTS = []
     t0 = time.perf_counter()
     for s in range(warmup, warmup + steps):
         step(s % len(pix))
     fence()
     dt = time.perf_counter() - t0
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     flop = RAYS * (N_COARSE + N_COARSE + N_FINE) * 2 * (593408 + 1151104)   # fwd + bwd, per rank
+    # roofline of the step's MFMA kernels from HIP events on the launch stream: record-mode forward launches and
+    # backward enqueues (dX chain + dW GEMMs + the two thin reduction kernels), against the fp32 MFMA peak
+    fwd = [(M, a.elapsed_time(b)) for tag, M, a, b in events if tag == "mlp_forward"]
+    bwd = [(M, a.elapsed_time(b)) for tag, M, a, b in events if tag == "mlp_backward"]
+    fwd_ms, bwd_ms = sum(t for _, t in fwd), sum(t for _, t in bwd)
+    fwd_tf = sum(M for M, _ in fwd) * 2 * 593408 / (fwd_ms * 1e-3) / 1e12
+    bwd_tf = sum(M for M, _ in bwd) * 2 * 1151104 / (bwd_ms * 1e-3) / 1e12
+    both = (sum(M for M, _ in fwd) * 2 * 593408 + sum(M for M, _ in bwd) * 2 * 1151104) / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": round(both, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(both / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": "mlp_forward_kernel<false,true> (record mode) + mlp_bwd_dx_kernel + mlp_bwd_dw_kernel",
+                "forward_record": {"ms_per_step": round(fwd_ms / steps, 3), "TFLOPs": round(fwd_tf, 1),
+                                   "frac": round(fwd_tf / FP32_MFMA_PEAK_TFLOPS, 4)},
+                "backward": {"ms_per_step": round(bwd_ms / steps, 3), "TFLOPs": round(bwd_tf, 1),
+                             "frac": round(bwd_tf / FP32_MFMA_PEAK_TFLOPS, 4)},
+                "other_ms_per_step": round(dt / steps * 1e3 - (fwd_ms + bwd_ms) / steps, 3)}
     return {"rays_per_s": world * RAYS * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
             "what": "fwd+bwd+fused Adam+ExponentialLR, both networks, 4096 rays x (64 + 192) samples per GPU"
                     + (f", gradient all-reduce over {world} ranks" if world > 1 else ""),
-            "mfma_frac_of_peak": flop / (dt / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+            "mfma_frac_of_peak": flop / (dt / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "roofline": roofline}
 
 
 def bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank, steps, warmup):

@@ -234,10 +234,13 @@ def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved,
     ws_bytes = lib.nerf_mlp_backward_workspace_bytes(M)
     ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=pos.device)
     with torch.cuda.device(pos.device):
+        end = _timed("mlp_backward", M)
         _lib.check(lib.nerf_mlp_backward(_ptr(packed), _ptr(flat_params), _ptr(pos), _ptr(view_dir), M,
                                          int(bool(encoded)), _ptr(sigma), _ptr(rgb), _ptr(saved),
                                          _ptr(g_sigma), _ptr(g_rgb), _ptr(g_params), _ptr(ws), _stream()),
                    "nerf_mlp_backward")
+        if end is not None:
+            end.record()
     return g_params
 
 
