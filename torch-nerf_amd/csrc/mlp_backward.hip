@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
                                                              const float *__restrict__ g_sigma,
                                                              const float *__restrict__ g_rgb,
                                                              const float *__restrict__ saved,
-                                                             float *__restrict__ dy) {
+                                                             float *__restrict__ dy,
+                                                             float *__restrict__ bias_partial) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -57,6 +58,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
     int offq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) offq[q] = chunk_slot_offset(i, 2 * q + h);
+    // sums over this lane's samples of the four scalar output gradients: d y10[0..2] (-> fc_out.bias) and
+    // d sigma' (-> fc_8.bias[0]); one partial per wavefront, summed in a fixed order by the reduction kernel
+    float bsum4[4] = {0.f, 0.f, 0.f, 0.f};
 
     Pipe pipe;
     pipe.src_wave = packed + BWD_OFFSET + wave * 8192;
@@ -97,6 +101,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         }
         // sigma = relu(y8[0]) (nerf.py:115)
         const float dsig = (valid && sigma[mc] > 0.0f) ? g_sigma[mc] : 0.0f;
+        if (h == 0) {   // the fc_out weight gradient is summed beside the fc_9 GEMM of the dW kernel, from this plane
+            const f32x4 g4 = {gy[0], gy[1], gy[2], 0.0f};
+            *reinterpret_cast<f32x4 *>(dy + gy_plane(MP) + 4 * m) = g4;
+            bsum4[0] += gy[0]; bsum4[1] += gy[1]; bsum4[2] += gy[2]; bsum4[3] += dsig;
+        }
 
         f32x16 acc[8], act[8];
 
@@ -182,6 +191,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
             save_plane<8>(dy + dy_plane(MP, 0), 256, m, h, act);
         }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = bsum4[c];   // lanes of half 1 hold zeros
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+        if (lane == 0) bias_partial[((int64_t)blockIdx.x * 4 + wave) * 4 + c] = v;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -189,9 +205,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 // stage 2: dW GEMMs
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_GEMMS = 13;
+constexpr int BIAS_PARTIAL_FLOATS = 1024 * 4 * 4;   // dX chain: up to 1024 workgroups x 4 waves x 4 sums
 constexpr int SLICE_EXTRA = 768;  // floats reserved after each partial tile: bias partial [256], density row [256], sum of dsig [1]
-constexpr int DW_LDS_BYTES = 131072 + 256;  // 2 stages of 64 KiB (wide X) or 3 stages of 40 KiB (thin X), + two dsig rows
-enum { FLAG_BIAS = 1, FLAG_DENSITY = 2 };   // FLAG_DENSITY: the fc_8 item also sums the density row (below)
+constexpr int DW_LDS_BYTES = 131072 + 1024;  // 2 stages of 64 KiB (wide X) or 3 stages of 40 KiB (thin X), + side-job rows
+enum { FLAG_BIAS = 1, FLAG_DENSITY = 2, FLAG_FCOUT = 4 };   // side jobs of the fc_8 / fc_9 items (dw_body)
 
 struct GemmDesc {
     int64_t a_off;        // dY plane, float offset into the dy workspace
@@ -224,6 +241,11 @@ __device__ __forceinline__ float lds_read_b32(unsigned lds_addr, int imm_offset)
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(imm_offset));
     return v;
 }
+__device__ __forceinline__ f32x4 lds_read_b128(unsigned lds_addr, int imm_offset) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(imm_offset));
+    return v;
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -244,7 +266,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // that also wait for the tile DMA: 16.8 instead of 8.8 ms; scalar loads at the point of use stall every k-step).
 // The sum of dsig itself (db8[0]) is left to the thin vector kernel, which reads 4 B/sample for it.  (Round 1 summed
 // the row in a separate HBM-bound kernel that read the whole h7 plane, 1 KB/sample, a second time: 0.2 ms per step.)
-template <int NA, int KB, int DWAVE = -1>   // DWAVE >= 0: the density side job, compiled for wave DWAVE
+// FWAVE (the fc_9 item, A = dY9, X = y8): the fc_out weight gradient rides along the same way --
+//   dWout[c][k] = sum_m gy[m][c] h9[m][k]   (3 x 128; nerf.py:119: rgb = sigmoid(fc_out(h9)))
+// -- h9 is the one activation plane no GEMM reads, so its 32-sample tiles (16 KiB) join the item's DMA stream as a third
+// operand; the three colour gradients come from the [sample][4] GY plane the dX chain wrote, through a 512-byte LDS
+// row filled one tile ahead by wave 0.  Wave w takes features 32 w .. 32 w + 31: one ds_read_b32 + one ds_read_b128 +
+// three v_fmac per k-step.  (Rounds 1-2a summed it in a separate HBM-bound kernel: 0.2 ms per step.)
+template <int NA, int KB, int DWAVE = -1, int FWAVE = -1>   // DWAVE / FWAVE >= 0: side job, compiled for that wave
 __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0, int64_t t1,
                                         const float *__restrict__ saved, const float *__restrict__ dy,
                                         float *__restrict__ partial, int64_t MP, char *lds, int tid, int lane,
@@ -253,19 +281,22 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
     constexpr int XW = 32 * KB;
     constexpr int A_PIECES = 32 * AW * 4 / 1024 / 4;  // 1-KiB DMA pieces per wave
     constexpr int X_PIECES = 32 * XW * 4 / 1024 / 4;  // per wave (X tile = 4 | 8 | 32 pieces)
-    constexpr int A_BYTES = 32 * AW * 4, X_BYTES = 32 * XW * 4;
-    constexpr int STAGE_BYTES = A_BYTES + X_BYTES;
+    constexpr bool FCOUT = FWAVE >= 0;
+    constexpr int H9_PIECES = FCOUT ? 32 * HALF * 4 / 1024 / 4 : 0;   // per wave: the 16-KiB h9 tile
+    constexpr int A_BYTES = 32 * AW * 4, X_BYTES = 32 * XW * 4, H9_BYTES = FCOUT ? 32 * HALF * 4 : 0;
+    constexpr int STAGE_BYTES = A_BYTES + X_BYTES + H9_BYTES;
     // thin X tiles finish their MFMAs faster than one DMA round trip: keep two tiles in flight
     constexpr int NSTAGE = (KB <= 2) ? 3 : 2;
     static_assert(NSTAGE * STAGE_BYTES <= DW_LDS_BYTES, "stage ring exceeds the LDS allocation");
-    static_assert(A_PIECES + X_PIECES <= 16, "one DMA piece per k-step");
-    constexpr int PER_WAVE = A_PIECES + X_PIECES;  // DMA instructions per wave per tile
+    static_assert(A_PIECES + X_PIECES + H9_PIECES <= 16, "one DMA piece per k-step");
+    constexpr int PER_WAVE = A_PIECES + X_PIECES + H9_PIECES;  // DMA instructions per wave per tile
     const int i = lane & 31, h = lane >> 5;
     const int frag_base = (i >> 3) * 256 + 4 * ((2 * h + ((i >> 2) & 1)) ^ (2 * ((i >> 3) & 1))) + (i & 3);
     const int frag_swing = 16 * (i >> 4);
     const bool want_bias = (g.flags & FLAG_BIAS) != 0;   // tiles [t0, t1) of the item; an empty range writes a zero partial
     const char *a_src = reinterpret_cast<const char *>(dy + g.a_off);      // wave-uniform; the lane offset rides
     const char *x_src = reinterpret_cast<const char *>(saved + g.x_off);   // in the DMA instruction's vector operand
+    const char *h9_src = reinterpret_cast<const char *>(saved + pl_h9(MP));
     const unsigned lane_off = (unsigned)lane * 16u;
     float *out = partial + g.partial_off + slice * slice_stride(g);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
@@ -288,6 +319,17 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
     // two 128-byte LDS rows behind the stages: row (t & 1) holds dsig of tile t
     const unsigned ds_rows = lds_base + NSTAGE * STAGE_BYTES;
     float ds_pend = 0.0f;   // wave 0: dsig[tile * 32 + i] of the tile AFTER the next one being staged
+    static_assert(!FCOUT || (NA == 1 && KB == 8 && NSTAGE == 2 && !DENSITY), "the fc_out side job belongs to the fc_9 item");
+    float wout[3] = {0.0f, 0.0f, 0.0f};
+    const float *gyp = dy + gy_plane(MP);
+    f32x4 gy_pend = {0.f, 0.f, 0.f, 0.f};   // wave 0: gy[tile * 32 + i] of the tile AFTER the next one being staged
+    // two 512-byte LDS rows behind the stages: row (t & 1) holds gy[.][0..3] of tile t
+    if (FCOUT && FWAVE == 0 && t0 < t1) {
+        f32x4 first;
+        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(first) : "v"(gyp + (t0 * 32 + i) * 4) : "memory");
+        if (h == 0) asm volatile("ds_write_b128 %0, %1" : : "v"(ds_rows + (unsigned)(t0 & 1) * 512u + 16u * i), "v"(first) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gy_pend) : "v"(gyp + ((t0 + 1 < t1 ? t0 + 1 : t1 - 1) * 32 + i) * 4) : "memory");
+    }
     if (DENSITY && DWAVE == 0 && t0 < t1) {
         // tile t0 goes straight into its row (visible after the first tile-top barrier), tile t0 + 1 is requested
         float first;
@@ -301,9 +343,12 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
         const unsigned ad = lds_base + buf * STAGE_BYTES;
         if (j < A_PIECES) {
             lds_dma_16s(a_src + t * A_BYTES + (wave + 4 * j) * 1024, lane_off, ad + (wave + 4 * j) * 1024);
-        } else {
+        } else if (j < A_PIECES + X_PIECES) {
             const int jx = j - A_PIECES;
             lds_dma_16s(x_src + t * X_BYTES + (wave + 4 * jx) * 1024, lane_off, ad + A_BYTES + (wave + 4 * jx) * 1024);
+        } else {
+            const int jh = j - A_PIECES - X_PIECES;
+            lds_dma_16s(h9_src + t * H9_BYTES + (wave + 4 * jh) * 1024, lane_off, ad + A_BYTES + X_BYTES + (wave + 4 * jh) * 1024);
         }
     };
     auto issue = [&](int64_t t, int buf) {
@@ -344,8 +389,17 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
             const int64_t t2 = t + 2 < t1 ? t + 2 : t1 - 1;
             asm volatile("global_load_dword %0, %1, off" : "=v"(ds_pend) : "v"(dsig + t2 * 32 + i) : "memory");
         }
+        if (FCOUT && FWAVE == 0) {   // same hand-off for the GY rows of the fc_out side job
+            if (h == 0) asm volatile("ds_write_b128 %0, %1" : : "v"(ds_rows + (unsigned)((t + 1) & 1) * 512u + 16u * i), "v"(gy_pend) : "memory");
+            const int64_t t2 = t + 2 < t1 ? t + 2 : t1 - 1;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gy_pend) : "v"(gyp + (t2 * 32 + i) * 4) : "memory");
+        }
         const unsigned ds_addr = ds_rows + (unsigned)(t & 1) * 128u + 4u * (unsigned)h;
-        float a[2][NA], b[2][KB], dval[2] = {0.0f, 0.0f};
+        const unsigned gy_addr = ds_rows + (unsigned)(t & 1) * 512u + 16u * (unsigned)h;
+        const unsigned h9_addr[2] = {stage + (unsigned)(A_BYTES + X_BYTES) + 4u * (unsigned)(frag_base + frag_swing),
+                                     stage + (unsigned)(A_BYTES + X_BYTES) + 4u * (unsigned)(frag_base - frag_swing)};
+        float a[2][NA], b[2][KB], dval[2] = {0.0f, 0.0f}, hval[2] = {0.0f, 0.0f};
+        f32x4 gyv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #define DW_FETCH(S)                                                                                   \
         {                                                                                             \
             _Pragma("unroll") for (int nb = 0; nb < NA; ++nb)                                         \
@@ -353,6 +407,10 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
             _Pragma("unroll") for (int kb = 0; kb < KB; ++kb)                                         \
                 b[(S) & 1][kb] = lds_read_b32(x_addr[(S) & 1], kb * 4096 + 64 * (S));                 \
             if (DENSITY) dval[(S) & 1] = lds_read_b32(ds_addr, 8 * (S));   /* dsig of sample 2 S + h */  \
+            if (FCOUT) {                                                                              \
+                hval[(S) & 1] = lds_read_b32(h9_addr[(S) & 1], (FCOUT ? FWAVE : 0) * 4096 + 64 * (S)); \
+                gyv[(S) & 1] = lds_read_b128(gy_addr, 32 * (S));            /* gy of sample 2 S + h */ \
+            }                                                                                         \
         }
         DW_FETCH(0)
         // dW += dY^T X over the 32 samples of the tile: 16 k-steps of 2 samples.  The A fragments
@@ -378,20 +436,34 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
                 for (int j = 0; j < 2; ++j)
                     asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(drow[j]) : "v"(dval[s & 1]), "v"(b[s & 1][2 * (DENSITY ? DWAVE : 0) + j]));
             }
+            if (FCOUT) {   // (asm volatile for the same reason)
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(wout[0]) : "v"(gyv[s & 1].x), "v"(hval[s & 1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(wout[1]) : "v"(gyv[s & 1].y), "v"(hval[s & 1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(wout[2]) : "v"(gyv[s & 1].z), "v"(hval[s & 1]));
+            }
         }
 #undef DW_FETCH
         buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     }
-    // partial tile of this slice: row-major [AW][XW], then bias[AW]
+    // partial tile of this slice: row-major [AW][XW], then bias[AW].  Stores in saddr form -- scalar row base (SALU),
+    // ONE lane register (4 h XW + i) * 4, the feature block in the immediate -- straight out of the accumulator
+    // registers.  (hipcc's own version of this loop precomputes 256 64-bit vector addresses, hoists them out of the
+    // item loop and spills them: 2.4 KB of scratch per lane.)
+    {
+        const unsigned lane_bytes = (unsigned)(4 * h * XW + i) * 4u;
 #pragma unroll
-    for (int nb = 0; nb < NA; ++nb)
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int nb = 0; nb < NA; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = wave * 32 * NA + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                out[n * XW + 32 * kb + i] = acc[nb][kb][r];
+                const float *row = out + (int64_t)(wave * 32 * NA + 32 * nb + (r & 3) + 8 * (r >> 2)) * XW;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    asm volatile("global_store_dword %0, %1, %2 offset:%3"
+                                 :
+                                 : "v"(lane_bytes), "a"(acc[nb][kb][r]), "s"(row), "n"(kb * 128)
+                                 : "memory");
             }
+    }
 #pragma unroll
     for (int nb = 0; nb < NA; ++nb) {
         const float both = bsum[nb] + __shfl_xor(bsum[nb], 32, WAVE);  // even + odd samples
@@ -402,6 +474,13 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
         for (int j = 0; j < 2; ++j) {
             const float both = drow[j] + __shfl_xor(drow[j], 32, WAVE);
             if (h == 0) out[AW * XW + 256 + 32 * (2 * (DENSITY ? DWAVE : 0) + j) + i] = both;
+        }
+    }
+    if (FCOUT) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float both = wout[c] + __shfl_xor(wout[c], 32, WAVE);
+            if (h == 0) out[AW * XW + 256 + c * HALF + 32 * (FCOUT ? FWAVE : 0) + i] = both;
         }
     }
 }
@@ -445,6 +524,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, con
             else if (wave == 1) dw_body<2, 8, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
             else if (wave == 2) dw_body<2, 8, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
             else dw_body<2, 8, 3>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        } else if (g.flags & FLAG_FCOUT) {
+            if (wave == 0) dw_body<1, 8, -1, 0>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+            else if (wave == 1) dw_body<1, 8, -1, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+            else if (wave == 2) dw_body<1, 8, -1, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+            else dw_body<1, 8, -1, 3>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         } else if (g.a_width == 256 && g.x_width == 256) dw_body<2, 8>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 256 && g.x_width == 64) dw_body<2, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 128 && g.x_width == 256) dw_body<1, 8>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
@@ -454,96 +538,27 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, con
     if (block_clocks && tid == 0) block_clocks[blockIdx.x] = wall_clock64() - clk0;  // 100 MHz ticks
 }
 
-// Thin outer-product sum on the vector ALU (an MFMA row block would be 3/32 used):
-//   fc_out   dW[c][k] = sum_m gy10[m][c] h9[m][k]  (3 x 128), db[c] = sum_m gy10[m][c]
-// Block b sums samples [b*chunk, (b+1)*chunk) with 8 rows in flight per thread group; HBM-bound: reads the h9
-// plane (512 B/sample) once.  (The other thin product, the density row of fc_8, rides on the fc_8 GEMM: dw_body.)
-constexpr int VEC_BLOCKS = 1024;   // per job
-constexpr int VEC_STRIDE = 512;    // floats per block partial: 388 used
-__global__ __launch_bounds__(256) void mlp_bwd_vec_kernel(const float *__restrict__ saved,
-                                                          const float *__restrict__ dy,
-                                                          const float *__restrict__ rgb,
-                                                          const float *__restrict__ g_rgb, int64_t M,
-                                                          float *__restrict__ partial_vec) {
-    __shared__ float red[2][3 * HALF + 4];
-    const int64_t MP = padded_rows(M);
-    const int job = blockIdx.y;
-    const int64_t chunk = (M + VEC_BLOCKS - 1) / VEC_BLOCKS;
-    const int64_t lo = blockIdx.x * chunk, hi = (lo + chunk < M) ? lo + chunk : M;
-    float *out = partial_vec + ((int64_t)job * VEC_BLOCKS + blockIdx.x) * VEC_STRIDE;
-    constexpr int U = 8;
-    const float *h9 = saved + pl_h9(MP);
-    const int k = threadIdx.x & (HALF - 1), grp = threadIdx.x >> 7;
-    float w[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
-    // db8[0] = sum_m dsig[m] (the density row's bias, nerf.py:113-115): threads k = 1 of both groups sum it on the side
-    const float *dsig = dy + dsig_plane(MP);
-    float dsum = 0.0f;
-    int64_t m = lo + grp;
-    for (; m + 2 * (U - 1) < hi; m += 2 * U) {
-        float x[U], gy[U][3], dsv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t mm = m + 2 * u;
-            dsv[u] = (k == 1) ? dsig[mm] : 0.0f;
-            x[u] = h9[tf_offset(HALF, mm, k)];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float y = rgb[3 * mm + c];
-                gy[u][c] = g_rgb[3 * mm + c] * y * (1.0f - y);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            dsum += dsv[u];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { w[c] = fmaf(gy[u][c], x[u], w[c]); b[c] += gy[u][c]; }
-        }
-    }
-    for (; m < hi; m += 2) {
-        if (k == 1) dsum += dsig[m];
-        const float x = h9[tf_offset(HALF, m, k)];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float y = rgb[3 * m + c];
-            const float gy = g_rgb[3 * m + c] * y * (1.0f - y);
-            w[c] = fmaf(gy, x, w[c]);
-            b[c] += gy;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        red[grp][c * HALF + k] = w[c];
-        if (k == 0) red[grp][3 * HALF + c] = b[c];
-    }
-    if (k == 1) red[grp][3 * HALF + 3] = dsum;
-    __syncthreads();
-    for (int e = threadIdx.x; e < 3 * HALF + 4; e += 256) out[e] = red[0][e] + red[1][e];
-}
-
 // ------------------------------------------------------------------------------------------
 // stage 3: reduce partial tiles into the flat gradient (state_dict layout), fixed order
 // ------------------------------------------------------------------------------------------
 __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__ partial,
-                                      const float *__restrict__ partial_vec, float *__restrict__ g_params) {
+                                      const float *__restrict__ bias_partial, int bias_partials,
+                                      float *__restrict__ g_params) {
     const int gi = blockIdx.y;
     const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    if (gi >= table.n) {  // the vector job (fc_out)
-        const int job = 0;
-        const int count = 3 * HALF + 4;
-        const float *src = partial_vec;
-        for (int64_t e = e0; e < count; e += step) {
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-            for (int b = 0; b < VEC_BLOCKS; b += 4) {
-                s0 += src[(int64_t)b * VEC_STRIDE + e];
-                s1 += src[(int64_t)(b + 1) * VEC_STRIDE + e];
-                s2 += src[(int64_t)(b + 2) * VEC_STRIDE + e];
-                s3 += src[(int64_t)(b + 3) * VEC_STRIDE + e];
-            }
-            const float s = (s0 + s1) + (s2 + s3);
-            (void)job;
-            if (e < 3 * HALF + 3) g_params[w_offset(10) + e] = s;  // fc_out weight (3,128) then bias (3): contiguous
-            else g_params[b_offset(8)] = s;                        // fc_8.bias[0]: sum of dsig
+    if (gi >= table.n) {  // the four scalar-output bias gradients: per-wavefront partials of the dX chain, fixed order
+        __shared__ float part[64][4];
+        if (blockIdx.x != 0) return;
+        const int c = threadIdx.x & 3, grp = threadIdx.x >> 2;   // 64 groups walk the partials with stride 64
+        float s0 = 0.0f;
+        for (int j = grp; j < bias_partials; j += 64) s0 += bias_partial[(int64_t)j * 4 + c];
+        part[grp][c] = s0;
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float t = 0.0f;
+            for (int q = 0; q < 64; ++q) t += part[q][threadIdx.x];
+            g_params[threadIdx.x < 3 ? b_offset(10) + threadIdx.x : b_offset(8)] = t;   // fc_out.bias[0..2], fc_8.bias[0]
         }
         return;
     }
@@ -552,7 +567,7 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
     const int64_t stride = slice_stride(g);
     const int64_t tile = (int64_t)g.a_width * g.valid_cols;
     const int64_t with_bias = tile + ((g.flags & FLAG_BIAS) ? g.a_width : 0);
-    const int64_t total = with_bias + ((g.flags & FLAG_DENSITY) ? FEAT : 0);
+    const int64_t total = with_bias + ((g.flags & FLAG_DENSITY) ? FEAT : (g.flags & FLAG_FCOUT) ? 3 * HALF : 0);
     for (int64_t e = e0; e < total; e += step) {
         int64_t src, dst;
         if (e < tile) {
@@ -563,10 +578,10 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
             const int n = (int)(e - tile);
             src = (int64_t)g.a_width * g.x_width + n;
             dst = g.b_off + g.row0 + n;
-        } else {   // density row of fc_8: weight[0, :]
+        } else {   // side-job rows: density row of fc_8 = weight[0, :]; fc_out.weight (3 x 128, contiguous)
             const int k = (int)(e - with_bias);
             src = (int64_t)g.a_width * g.x_width + 256 + k;
-            dst = g.w_off + k;
+            dst = (g.flags & FLAG_DENSITY) ? g.w_off + k : w_offset(10) + k;
         }
         float s = 0.0f;
         for (int sl = 0; sl < g.num_slices; ++sl) s += base[sl * stride + src];
@@ -603,7 +618,7 @@ Plan make_plan(int64_t M, int cus) {
     add(6, dy_plane(MP, 6), 256, pl_h(MP, 5), 256, 0, 256, 0, FLAG_BIAS);
     add(7, dy_plane(MP, 7), 256, pl_h(MP, 6), 256, 0, 256, 0, FLAG_BIAS);
     add(8, dy_plane(MP, 8), 256, pl_h(MP, 7), 256, 0, 256, 1, FLAG_BIAS | FLAG_DENSITY);
-    add(9, dy9_plane(MP), 128, pl_y8(MP), 256, 0, 256, 0, FLAG_BIAS);
+    add(9, dy9_plane(MP), 128, pl_y8(MP), 256, 0, 256, 0, FLAG_BIAS | FLAG_FCOUT);
     add(9, dy9_plane(MP), 128, pl_de(MP), 32, FEAT, E_DIR, 0, 0);
     T.n = n;
     // Relative time of one 32-row tile per item shape (measured on MI355X with all CUs busy, ns; scripts/dw_timing.py):
@@ -612,8 +627,8 @@ Plan make_plan(int64_t M, int cus) {
     int64_t units = 0;
     for (int k = 0; k < n; ++k) {
         const int aw = T.g[k].a_width, xw = T.g[k].x_width;
-        T.g[k].cost = (T.g[k].flags & FLAG_DENSITY) ? 7450 : (aw == 256 && xw == 256) ? 7350 : (aw == 256 && xw == 64) ? 2010
-                    : (aw == 128 && xw == 256) ? 3770 : 935;
+        T.g[k].cost = (T.g[k].flags & FLAG_DENSITY) ? 7450 : (T.g[k].flags & FLAG_FCOUT) ? 4130 : (aw == 256 && xw == 256) ? 7350
+                    : (aw == 256 && xw == 64) ? 2010 : (aw == 128 && xw == 256) ? 3770 : 935;
         T.g[k].unit_off = units;
         units += tiles * T.g[k].cost;
     }
@@ -649,7 +664,7 @@ NERF_API int64_t nerf_mlp_backward_workspace_bytes(int64_t M) {
     const int64_t MP = mlp::padded_rows(M);
     // upper bound on the partial buffer that does not depend on the device: 2 x 256 slices of a full tile
     const int64_t partial = (int64_t)(2 * 256 + MAX_GEMMS) * (256 * 256 + SLICE_EXTRA);
-    return 4 * (align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE) + partial + (int64_t)2 * VEC_BLOCKS * VEC_STRIDE);
+    return 4 * (align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE) + partial + (int64_t)BIAS_PARTIAL_FLOATS);
 }
 
 NERF_API int nerf_mlp_backward(const void *packed, const float *params, const float *pos,
@@ -679,13 +694,13 @@ NERF_API int nerf_mlp_backward(const void *packed, const float *params, const fl
     float *dy = static_cast<float *>(workspace);
     float *partial = dy + align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE);
     const Plan plan = make_plan(M, cus);
-    float *partial_vec = partial + plan.partial_floats;
+    float *bias_partial = partial + plan.partial_floats;
     const float *sv = static_cast<const float *>(saved);
 
     const int64_t ntiles = MP / mlp::TILE_SAMPLES;
-    hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(256),
-                       mlp::LDS_BYTES, s, static_cast<const char *>(packed), M, sigma, rgb, g_sigma, g_rgb, sv,
-                       dy);
+    const unsigned dx_grid = (unsigned)(ntiles < cus ? ntiles : (cus < 1024 ? cus : 1024));
+    hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(dx_grid), dim3(256), mlp::LDS_BYTES, s,
+                       static_cast<const char *>(packed), M, sigma, rgb, g_sigma, g_rgb, sv, dy, bias_partial);
     int rc = nerf::check_launch("nerf_mlp_backward: dx chain");
     if (rc != NERF_OK) return rc;
     // NERF_DW_TIMING=<file>: debugging aid, dumps per-workgroup durations of the dW kernel (syncs!)
@@ -711,11 +726,8 @@ NERF_API int nerf_mlp_backward(const void *packed, const float *params, const fl
             fclose(f);
         }
     }
-    hipLaunchKernelGGL(mlp_bwd_vec_kernel, dim3(VEC_BLOCKS, 1), dim3(256), 0, s, sv, static_cast<const float *>(dy), rgb,
-                       g_rgb, M, partial_vec);
-    rc = nerf::check_launch("nerf_mlp_backward: vector sums");
-    if (rc != NERF_OK) return rc;
     hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(64, plan.table.n + 1), dim3(256), 0, s, plan.table,
-                       static_cast<const float *>(partial), static_cast<const float *>(partial_vec), g_params);
+                       static_cast<const float *>(partial), static_cast<const float *>(bias_partial), (int)dx_grid * 4,
+                       g_params);
     return nerf::check_launch("nerf_mlp_backward: reduce");
 }

@@ -127,7 +127,9 @@ __host__ __device__ constexpr int64_t pl_masks(int64_t MP) { return MP * SAVED_F
 __host__ __device__ constexpr int64_t dy_plane(int64_t MP, int l) { return MP * 256 * (int64_t)l; }  // l = 0..8
 __host__ __device__ constexpr int64_t dy9_plane(int64_t MP) { return MP * 256 * 9; }
 __host__ __device__ constexpr int64_t dsig_plane(int64_t MP) { return MP * (256 * 9 + 128); }
-constexpr int DY_FLOATS_PER_SAMPLE = 256 * 9 + 128 + 1;
+//   GY              : grad w.r.t. the three pre-sigmoid colours, [sample][4] (the 4th float is zero) (4/sample)
+__host__ __device__ constexpr int64_t gy_plane(int64_t MP) { return MP * (256 * 9 + 128 + 1); }
+constexpr int DY_FLOATS_PER_SAMPLE = 256 * 9 + 128 + 1 + 4;
 
 // ---- bf16 inference stream (BASELINE configs[2]: bf16 weights on v_mfma_f32_32x32x16_bf16).
 // [const block (fp32, as above)][sub-step 0]...[sub-step 36]; a sub-step = 32 KiB = what one pipeline step of
