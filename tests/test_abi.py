@@ -51,3 +51,13 @@ def test_plane_layout_is_a_bijection_with_coalesced_stores_and_conflict_free_fra
                     banks = {int(off[2 * s + h, 32 * fb + i]) % 32 for i in range(32)}
                     assert len(banks) == 32
     assert lib.nerf_mlp_plane_offset(100, 0, 0) == -1 and lib.nerf_mlp_plane_offset(256, 0, 256) == -1
+
+
+def test_render_is_fused_is_a_host_side_rule():
+    """Which sample counts run as the single-kernel pass (csrc/render_fused.hip): G in {1, 2, 4} rays whose samples are
+    a whole number of 128-sample tiles, rows fitting the LDS left beside the weight ring.  Pure host logic."""
+    lib = _lib.load()
+    for sc, sf, fine, want in [(64, 128, 0, 1), (64, 128, 1, 1), (64, 0, 0, 1), (128, 64, 1, 1), (64, 64, 1, 1),
+                               (32, 0, 0, 1), (32, 64, 1, 1), (64, 192, 1, 1),
+                               (40, 0, 0, 0), (40, 24, 1, 1), (1000, 16, 1, 0), (100, 0, 0, 0), (0, 0, 0, 0), (64, -1, 1, 0)]:
+        assert lib.nerf_render_is_fused(sc, sf, fine) == want, (sc, sf, fine)
