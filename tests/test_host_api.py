@@ -153,3 +153,18 @@ def test_synthetic_generators_are_deterministic():
     assert len(synth.blender_orbit_poses()) == 40
     p = synth.pixel_batch(0, 800, 800, 4096)
     assert p.dtype == np.int64 and len(set(p.tolist())) == 4096
+
+
+def test_sampler_draws_follow_the_reference_order():
+    """U1 (N,Sc) -> U2 (N,Sf) -> U3 (N,Sf) with torch.rand, as stratified_sampler.py:77 / utils.py:43,56 draw them:
+    a seed reproduces the reference's stream on the same device, for the step-by-step and the fused path alike."""
+    s = ray_samplers.StratifiedSampler()
+    torch.manual_seed(11)
+    u1, u2, u3 = s.draw_uniforms(5, 64, 128, "cpu")
+    torch.manual_seed(11)
+    want = (torch.rand((5, 64)), torch.rand((5, 128)), torch.rand((5, 128)))
+    assert all(torch.equal(a, b) for a, b in zip((u1, u2, u3), want))
+    torch.manual_seed(11)
+    c1, c2, c3 = s.draw_uniforms(5, 64, 0, "cpu")
+    assert torch.equal(c1, want[0]) and c2 is None and c3 is None
+    assert s.check_sample_counts(64, None) == (64, 0) and s.check_sample_counts((64, 128), torch.ones(1, 64)) == (64, 128)

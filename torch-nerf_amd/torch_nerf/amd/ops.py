@@ -378,6 +378,8 @@ def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, 
     encode + MLP and the integral, with no intermediate in HBM.  `weights` (fine pass) is floored in place.
     bf16=True: `packed` is a mlp_pack_bf16 stream and the MLP runs on the bf16 MFMA path (three launches)."""
     if bf16:
+        if want_idx or want_t:
+            raise ValueError("render_rays(bf16=True) returns (rgb, weights) only: ask sample_hierarchical for idx / t")
         if weights is None:
             pts, dirs, delta = sample_stratified(ray_o, ray_d, t_bins, partition_size, u1)
         else:
