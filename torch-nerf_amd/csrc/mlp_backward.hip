@@ -7,16 +7,18 @@
 //     32 samples per wavefront, dY^T(l-1) = W_l^T dY^T(l) on v_mfma_f32_32x32x2_f32 with the
 //     TRANSPOSED weight chunks streamed through the LDS ring -- ReLU masks come from the
 //     bit planes the training-mode forward saved; every layer's pre-activation gradient is
-//     written once to a row-major plane.  8704 MFMAs per 32 samples.
+//     written once to a tile-fragment plane (mlp_layout.h).  8704 MFMAs per 32 samples.  It also leaves the
+//     [sample][4] plane of colour gradients and per-wavefront sums of the four scalar output gradients.
 //  2. dW GEMMs   (mlp_bwd_dw_kernel): dW_l = dY_l^T X_l with the sample axis as the MFMA
-//     reduction dimension.  A workgroup owns one (layer, sample-slice) item, keeps the whole
-//     256 x K_l tile in accumulators (up to 256 VGPRs per lane), and streams 32-row tiles of
-//     dY and X -- contiguous in HBM -- into a double-buffered LDS stage by LDS-DMA.
-//     Bias gradients ride along for free: the A fragments ARE the dY values to be summed.
-//     2 KB of HBM reads per sample-layer for 131 kFLOP: intensity 64 FLOP/B, MFMA-bound.
-//  3. thin outer products on the vector ALU (mlp_bwd_vec_kernel: fc_out 3 x 128 and the density
-//     row of fc_8), then a deterministic reduction of all per-slice / per-block partials into the
-//     flat gradient blob (state_dict layout).  No atomics anywhere: gradients are reproducible.
+//     reduction dimension.  A workgroup owns a work interval of the concatenated (layer, tile) items, keeps
+//     the whole 256 x K_l tile in accumulators (256 AGPRs), and streams 32-row tiles of dY and X --
+//     contiguous in HBM -- into a double-buffered LDS stage by LDS-DMA.  The layer bias gradients ride along
+//     (the A fragments ARE the dY values to be summed), and so do the two thin outer products an MFMA block
+//     would waste -- the density row of fc_8 on the fc_8 item, fc_out (3 x 128) on the fc_9 item -- as a
+//     few vector FMAs per k-step.  2 KB of HBM reads per sample-layer for 131 kFLOP: 64 FLOP/B, MFMA-bound.
+//  3. a deterministic reduction (mlp_bwd_reduce_kernel) of all per-workgroup partial tiles and the dX chain's
+//     scalar sums into the flat gradient blob (state_dict layout).  No atomics anywhere: gradients are
+//     reproducible bit for bit.
 #include <stdlib.h>
 #include <vector>
 
@@ -264,7 +266,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // choice of fragments becomes branches in the k-loop), and dsig reaches the lanes through a 128-byte LDS row that
 // wave 0 fills one tile ahead from a HAND-ISSUED load (a compiler-visible load makes hipcc insert vmcnt waits
 // that also wait for the tile DMA: 16.8 instead of 8.8 ms; scalar loads at the point of use stall every k-step).
-// The sum of dsig itself (db8[0]) is left to the thin vector kernel, which reads 4 B/sample for it.  (Round 1 summed
+// The sum of dsig itself (db8[0]) comes from the dX chain's per-wavefront sums.  (Round 1 summed
 // the row in a separate HBM-bound kernel that read the whole h7 plane, 1 KB/sample, a second time: 0.2 ms per step.)
 // FWAVE (the fc_9 item, A = dY9, X = y8): the fc_out weight gradient rides along the same way --
 //   dWout[c][k] = sum_m gy[m][c] h9[m][k]   (3 x 128; nerf.py:119: rgb = sigmoid(fc_out(h9)))
