@@ -56,13 +56,14 @@ frame(); torch.cuda.synchronize()
 if args.llff and args.spiral > 0:   # row f3: walk the render path the LLFF loader would hand to runners/render.py
     import numpy as np
     poses, bounds = synth.llff_like_pose_set(20, seed=0)
-    path = synth.llff_spiral_poses(synth.recenter_poses(poses), bounds)
+    path = synth.llff_spiral_poses(poses, bounds)   # (not recentred: the path stays one unit off the z = 0 plane, see synth)
     for k in np.linspace(0, len(path), args.spiral, endpoint=False).astype(int):
         cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
                                         torch.from_numpy(path[k]), 0.0, 1.0)
         t0 = time.perf_counter(); img = frame(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         if int(os.environ.get("RANK", "0")) == 0:
-            print(f"spiral pose {k:3d}/{len(path)}: {dt*1e3:.1f} ms, mean colour {img.mean(0).tolist()}", flush=True)
+            print(f"spiral pose {k:3d}/{len(path)}: {dt*1e3:.1f} ms, mean colour {[round(c, 4) for c in img.mean(0).tolist()]}, "
+                  f"finite {bool(torch.isfinite(img).all())}", flush=True)
             if args.png:
                 image.save_png(args.png % k if "%" in args.png else args.png, img.view(H, W, 3))
 t0 = time.perf_counter(); img = frame(); torch.cuda.synchronize(); dt = time.perf_counter() - t0

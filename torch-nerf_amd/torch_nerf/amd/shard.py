@@ -109,7 +109,7 @@ def allreduce_gradients(parameters, group: Optional[dist.ProcessGroup] = None, a
 
 @torch.no_grad()
 def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, project_to_ndc: bool, seed: int,
-                 group: Optional[dist.ProcessGroup] = None, rays_per_launch: int = 65536,
+                 group: Optional[dist.ProcessGroup] = None, rays_per_launch: int = 131072,
                  bf16: bool = False, single_rank: bool = False) -> torch.Tensor:
     """Full frame (H*W, 3) on every rank; each rank renders only its pixel range on its own GPU.
     single_rank=True: the calling rank renders the whole frame alone, no collective (the 1-GPU image a sharded
@@ -130,8 +130,13 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
     if bf16:  # BASELINE configs[2]: bf16 weights / layer inputs on the bf16 MFMA path
         packed_c, packed_f = ops.mlp_pack_bf16(flat_c), ops.mlp_pack_bf16(flat_f)
     out = torch.empty((hi - lo, 3), dtype=torch.float32, device=device)
-    for first in range(lo, hi, rays_per_launch):
-        n = min(rays_per_launch, hi - first)
+    # equal launches of at most rays_per_launch rays (a multiple of 4: the fused pass walks bunches of four rays): the
+    # persistent kernel then ends every launch with the same, small, last-round imbalance instead of one short tail
+    launches = max(1, -(-(hi - lo) // max(1, rays_per_launch)))
+    per_launch = -(-(hi - lo) // launches)
+    per_launch = min(max(4, (per_launch + 3) // 4 * 4), max(4, rays_per_launch))
+    for first in range(lo, hi, per_launch):
+        n = min(per_launch, hi - first)
         bundle = sampler.generate_rays_from_pixels(camera, project_to_ndc, first=first, count=n, device=device)
         u1c, u1, u2, u3 = ray_draws(seed, first, n, n_coarse, n_fine, device)
         _, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, bf16=bf16)

@@ -188,11 +188,12 @@ def llff_spiral_poses(extrinsics, z_bounds, path_zflat=False):
 
 def llff_like_pose_set(num=20, seed=0):
     """(poses (num,3,4) float64, z_bounds (num,2)): a forward-facing capture like an LLFF scene -- cameras on a
-    jittered grid in front of the scene, all looking roughly down -z -- from the build's counter generator."""
+    jittered grid one unit in front of the z = 0 plane, all looking roughly down -z -- from the build's counter
+    generator.  (One unit away: the reference's NDC mapping divides by the origin's z, sampler_base.py:199-257.)"""
     u = counter_uniform(seed, 77, num * 8).astype(np.float64).reshape(num, 8)
     poses = []
     for k in range(num):
-        position = np.array([(u[k, 0] - 0.5) * 2.0, (u[k, 1] - 0.5) * 1.2, (u[k, 2] - 0.5) * 0.3])
+        position = np.array([(u[k, 0] - 0.5) * 2.0, (u[k, 1] - 0.5) * 1.2, 1.0 + (u[k, 2] - 0.5) * 0.3])
         look = np.array([(u[k, 3] - 0.5) * 0.2, (u[k, 4] - 0.5) * 0.2, 1.0])      # camera z axis points backwards
         poses.append(build_extrinsic(look, np.array([(u[k, 5] - 0.5) * 0.1, 1.0, 0.0]), position))
     z_bounds = np.stack([1.2 + u[:, 6], 8.0 + 6.0 * u[:, 7]], axis=1)
