@@ -52,6 +52,40 @@ __device__ __forceinline__ float enc_feature(int k, float x, float y, float z, i
     return k < 3 ? v : (k < kmax ? t : 0.0f);
 }
 
+// All NF (64 | 32) encoding features of one sample, tail beyond 3 + 6 LEVELS zero: ONE sincos per (octave, channel)
+// gives both its sin and its cos feature -- the same sincos_cw<false>(ldexpf(v, f)) that enc_feature evaluates, so the
+// values are bit-identical to it.  Every index is a compile-time constant.  (fp32 MFMAs and vector instructions share
+// the SIMD lanes -- DESIGN.md section 4.2 -- so the encodings are paid in full: enc_feature per needed feature costs
+// 48 evaluations + run-time index arithmetic per lane and tile, ~1.6 k instructions; this table + the per-half select
+// below ~1.1 k.)
+template <int LEVELS, int NF>
+__device__ __forceinline__ void encode_table(float x, float y, float z, float (&F)[NF]) {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) F[k] = 0.0f;
+    const float v[3] = {x, y, z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) F[c] = v[c];
+#pragma unroll
+    for (int f = 0; f < LEVELS; ++f)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s, co;
+            sincos_cw<false>(ldexpf(v[c], f), s, co);
+            F[3 + 6 * f + c] = s;
+            F[3 + 6 * f + 3 + c] = co;
+        }
+}
+
+// B-fragment registers of encoding block `blk` for lane half h: register r <-> feature 32 blk + (r&3) + 8 (r>>2) + 4 h
+template <int NF>
+__device__ __forceinline__ void table_to_fragment(const float (&F)[NF], int blk, int h, f32x16 &frag) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = 32 * blk + (r & 3) + 8 * (r >> 2);
+        frag[r] = h ? F[k + 4] : F[k];
+    }
+}
+
 // largest |argument| the encodings of this sample will see: 2^(L-1) * max|coordinate|
 __device__ __forceinline__ bool encoding_needs_exact(const float (&raw)[6]) {
     const float p = fmaxf(fmaxf(fabsf(raw[0]), fabsf(raw[1])), fabsf(raw[2]));

@@ -48,12 +48,16 @@ __device__ __forceinline__ void forward_tile(const float (&raw)[6], const float 
             de[r] = enc_feature<true>(k, raw[3], raw[4], raw[5], E_DIR);
         }
     } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
-            pe[0][r] = enc_feature<false>(k, raw[0], raw[1], raw[2], E_POS);
-            pe[1][r] = enc_feature<false>(32 + k, raw[0], raw[1], raw[2], E_POS);
-            de[r] = enc_feature<false>(k, raw[3], raw[4], raw[5], E_DIR);
+        {
+            float F[64];
+            encode_table<L_POS, 64>(raw[0], raw[1], raw[2], F);
+            table_to_fragment(F, 0, h, pe[0]);
+            table_to_fragment(F, 1, h, pe[1]);
+        }
+        {
+            float F[32];
+            encode_table<L_DIR, 32>(raw[3], raw[4], raw[5], F);
+            table_to_fragment(F, 0, h, de);
         }
     }
     after_encode();
