@@ -25,12 +25,14 @@ The JSON line also carries
   ms_per_step_median : median of per-step HIP-event times (the headline value stays total rays / total time)
 """
 import argparse
+import datetime
 import hashlib
 import json
 import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -335,24 +337,31 @@ def hbm_stages(device, reps=20):
     return out
 
 
-def frame_leg(nets, cam, rank, world, device):
+def frame_leg(nets, cam, rank, world, device, dist_on=None):
     """BASELINE configs[4]: one 800x800 frame (640 000 rays, 64+128), pixel ranges sharded over the ranks, each rank
-    renders coarse+fine for its range and ONE all-gather assembles the image (shard.render_frame).  Strong scaling."""
+    renders coarse+fine for its range and ONE all-gather assembles the image (shard.render_frame).  Strong scaling.
+    With world > 1 EVERY rank first renders the whole frame alone (no collective, nobody idles inside the process
+    group's watchdog window); the gathered image must then equal that one-rank image bit for bit on every rank."""
     from torch_nerf.amd import shard
+    dist_on = world > 1 if dist_on is None else dist_on
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
-    shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1)      # warm-up
+    solo = None
+    if dist_on:     # doubles as the warm-up; draws are a function of the global ray index, so the bits must agree
+        solo = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1, single_rank=True)
+        torch.cuda.synchronize()
+    shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1)      # warm-up (collective included)
     fence()
     t0 = time.perf_counter()
     img = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -361,15 +370,156 @@ def frame_leg(nets, cam, rank, world, device):
            "image_sha256_16": digest,
            "what": f"{W}x{H} frame, 64+128 samples, fp32, contiguous pixel ranges over {world} rank(s), "
                    "all-gather of the (H*W/world, 3) slabs included"}
-    if world > 1:
-        # the same frame rendered by rank 0 alone must be the same bits (draws are a function of the global ray index)
-        same = torch.ones(1, device=device)
-        if rank == 0:
-            solo = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1, single_rank=True)
-            out["image_sha256_16_one_rank"] = hashlib.sha256(solo.cpu().numpy().tobytes()).hexdigest()[:16]
-            same.fill_(float(torch.equal(solo, img)))
-        dist.broadcast(same, 0)
+    if dist_on:
+        out["image_sha256_16_one_rank"] = hashlib.sha256(solo.cpu().numpy().tobytes()).hexdigest()[:16]
+        same = torch.tensor([float(torch.equal(solo, img))], device=device)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)          # equal on EVERY rank
         out["equals_one_rank_image"] = bool(same.item())
+    return out
+
+
+def runner_loop_leg(device, local_rank, steps, warmup):
+    """The per-batch body of the reference's train_one_epoch (runners/train.py:120-218), statement by statement,
+    against the drop-in classes -- what an UNMODIFIED runner pays per step: a fresh PerspectiveCamera per batch,
+    np.random.choice(H*W, 4096, replace=False) inside render_scene, the CPU ground-truth gather + .cuda() upload,
+    three .item() syncs, torch.optim.Adam + ExponentialLR.  Host pieces are timed one by one (perf_counter around
+    the statement; the .item() figures are mostly the GPU work they wait for)."""
+    import torch_nerf.src.renderer.cameras as cameras
+    renderer, scene_c, scene_f, nets, _, _, focal, _ = build_scene(device)
+    from torch_nerf.amd import synth
+    params = [p for net in nets for p in net.parameters()]
+    optimizer = torch.optim.Adam(params, lr=5e-4, eps=1e-8)                      # runner_utils.py:691-695
+    scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, pow(0.00005 / 0.0005, 1 / 300000))
+    loss_func = torch.nn.MSELoss()
+    views = [(torch.rand((H, W, 3)), torch.from_numpy(synth.pose_spherical(a, -30.0, 4.0))) for a in (10.0, 130.0, 250.0)]
+    np.random.seed(0)
+    clock = {k: 0.0 for k in ("camera", "render_coarse_call", "gt_gather_upload", "item_syncs", "render_fine_call",
+                              "backward_call", "adam_call")}
+
+    def tick(key, t0):
+        clock[key] += time.perf_counter() - t0
+
+    def step(k, timed):
+        pixel_gt, extrinsic = views[k % len(views)]
+        pixel_gt = pixel_gt.squeeze().reshape(-1, 3)
+        loss = 0.0
+        optimizer.zero_grad()
+        t0 = time.perf_counter()
+        renderer.camera = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
+                                                    extrinsic, NEAR, FAR)
+        if timed: tick("camera", t0)
+        t0 = time.perf_counter()
+        coarse_pred, coarse_indices, coarse_weights = renderer.render_scene(
+            scene_c, num_pixels=RAYS, num_samples=N_COARSE, project_to_ndc=False, pixel_indices=None,
+            device=torch.cuda.current_device())
+        if timed: tick("render_coarse_call", t0)
+        t0 = time.perf_counter()
+        gt_c = pixel_gt[coarse_indices, ...].cuda()
+        if timed: tick("gt_gather_upload", t0)
+        coarse_loss = loss_func(gt_c, coarse_pred)
+        loss += coarse_loss
+        t0 = time.perf_counter()
+        coarse_loss.item()
+        if timed: tick("item_syncs", t0)
+        t0 = time.perf_counter()
+        fine_pred, fine_indices, _ = renderer.render_scene(
+            scene_f, num_pixels=RAYS, num_samples=(N_COARSE, N_FINE), project_to_ndc=False,
+            pixel_indices=coarse_indices, weights=coarse_weights, device=torch.cuda.current_device())
+        if timed: tick("render_fine_call", t0)
+        t0 = time.perf_counter()
+        gt_f = pixel_gt[fine_indices, ...].cuda()
+        if timed: tick("gt_gather_upload", t0)
+        fine_loss = loss_func(gt_f, fine_pred)
+        loss += fine_loss
+        t0 = time.perf_counter()
+        fine_loss.item()
+        loss.item()
+        if timed: tick("item_syncs", t0)
+        t0 = time.perf_counter()
+        loss.backward()
+        if timed: tick("backward_call", t0)
+        t0 = time.perf_counter()
+        optimizer.step()
+        scheduler.step()
+        if timed: tick("adam_call", t0)
+
+    for k in range(warmup):
+        step(k, False)
+    torch.cuda.synchronize()
+    t_choice0 = time.perf_counter()
+    for _ in range(5):
+        np.random.choice(H * W, size=[RAYS], replace=False)
+    choice_ms = (time.perf_counter() - t_choice0) / 5 * 1e3
+    t0 = time.perf_counter()
+    for k in range(warmup, warmup + steps):
+        step(k, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": dt / steps * 1e3, "rays_per_s": RAYS * steps / dt, "steps": steps,
+            "host_ms_per_step": {k: round(v / steps * 1e3, 3) for k, v in clock.items()},
+            "np_random_choice_ms": round(choice_ms, 3),
+            "what": "runners/train.py:120-218 verbatim against the drop-in classes: camera per batch, np.random.choice "
+                    "pixel batch, CPU ground-truth gather + upload, three .item() syncs, torch.optim.Adam + "
+                    "ExponentialLR; compare with train.ms_per_step (device-resident batch, FusedAdam, no syncs)"}
+
+
+def configs_leg(nets, flats, device):
+    """Driver-run numbers for the remaining BASELINE configs.
+    llff      (configs[3]): 1008x756 forward-facing frame, NDC rays, t in [0,1], 64+128, through shard.render_frame.
+    coarse400 (configs[0]): 400x400 Blender frame, coarse-only 64 samples: the whole frame on the GPU, and the CPU
+                            port (oracle/torch_port.py) on a bounded run of the SAME rays and draws beside it."""
+    import torch_nerf.src.renderer.cameras as cameras
+    from oracle import torch_port as TP
+    from torch_nerf.amd import shard, synth
+    out = {}
+    # ---- configs[3]
+    Hl, Wl, fl = 756, 1008, 815.0
+    cam = cameras.PerspectiveCamera({"f_x": fl, "f_y": fl, "img_width": Wl, "img_height": Hl},
+                                    torch.from_numpy(synth.llff_like_pose()), 0.0, 1.0)
+    shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, True, seed=2, single_rank=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    img = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, True, seed=2, single_rank=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["llff"] = {"ms": dt * 1e3, "rays_per_s": Hl * Wl / dt, "rays": Hl * Wl, "finite": bool(torch.isfinite(img).all()),
+                   "image_sha256_16": hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()[:16],
+                   "what": "LLFF fern geometry 1008x756, NDC rays, t in [0,1], 64+128, fp32, 1 GPU, full frame"}
+    # ---- configs[0]
+    Hc = Wc = 400
+    fc = float(synth.blender_focal(Wc))
+    pose = torch.from_numpy(synth.pose_spherical(37.0, -30.0, 4.0))
+    cam = cameras.PerspectiveCamera({"f_x": fc, "f_y": fc, "img_width": Wc, "img_height": Hc}, pose, NEAR, FAR)
+    shard.render_frame(cam, nets[0], nets[1], N_COARSE, 0, False, seed=3, single_rank=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    img = shard.render_frame(cam, nets[0], nets[1], N_COARSE, 0, False, seed=3, single_rank=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    p = {k: torch.from_numpy(v.copy()) for k, v in synth.split_flat_params(flats[0]).items()}
+
+    def cpu(n_rays):
+        pix = torch.arange(n_rays)
+        u1c = shard.ray_draws(3, 0, n_rays, N_COARSE, 0, "cpu")[0]
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            o, d = TP.rays(pix, Hc, Wc, fc, pose)
+            rgb, _, _ = TP.render_pass(p, o, d, NEAR, FAR, N_COARSE, u1c)
+        return time.perf_counter() - t0, rgb
+
+    cpu(256)
+    t_probe, _ = cpu(1024)
+    n = int(min(Hc * Wc, max(1024, 1024 * (10.0 / max(t_probe, 1e-3))))) // 1024 * 1024    # ~10 s of CPU work
+    secs, rgb_cpu = cpu(n)
+    err = (img[:n].cpu() - rgb_cpu).abs().max().item()
+    out["coarse400"] = {"ms": dt * 1e3, "rays_per_s": Hc * Wc / dt, "rays": Hc * Wc,
+                        "cpu_port": {"value": n / secs, "unit": "rays/s", "cores": cores, "kind": "port",
+                                     "sample": f"the first {n} of the frame's 160000 rays, same draws, {secs:.1f} s"},
+                        "max_abs_pixel_err_vs_cpu_port": err, "speedup_vs_cpu_port": (Hc * Wc / dt) / (n / secs),
+                        "what": "Blender lego geometry 400x400, coarse-only 64 samples, fp32, whole frame on 1 GPU; "
+                                "the reference's own CPU-runnable case restated by oracle/torch_port.py beside it"}
     return out
 
 
@@ -399,8 +549,17 @@ def main():
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-MFMA render measurement")
     ap.add_argument("--no-frame", action="store_true", help="skip the 800x800 sharded full-frame leg")
     ap.add_argument("--no-stages", action="store_true", help="skip the HBM-bound stage measurements")
+    ap.add_argument("--no-configs", action="store_true", help="skip the llff (configs[3]) and coarse400 (configs[0]) legs")
+    ap.add_argument("--no-runner-loop", action="store_true", help="skip the runners/train.py-shaped training loop leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and issue every collective "
+                    "of the N-rank path even with ONE rank (RCCL init with device_id, all_gather_into_tensor, all_reduce, "
+                    "barrier on a 1-GPU box; tests/test_bench_launch.py)")
+    ap.add_argument("--dist-timeout", type=int, default=120, help="process-group timeout in seconds: a stuck "
+                    "collective ends the run with rc != 0 instead of hanging it")
+    ap.add_argument("--leg-timeout", type=int, default=420, help="with a process group up: seconds the secondary legs "
+                    "may take after the headline line is out before the process leaves with rc 3")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous, collectives and the JSON line only, no "
                     "rendering: exercises the self-launch and the N-rank plumbing on a box without GPUs (CPU tests)")
     args = ap.parse_args()
@@ -432,11 +591,19 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     ranks_seen = 1
-    if world > 1:
+    dist_on = world > 1 or args.force_dist       # every `if dist_on` below is a collective of the N-rank path
+    if dist_on:
+        if "MASTER_ADDR" not in os.environ:      # --force-dist outside a launcher: a one-rank rendezvous on loopback
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0",
+                                  WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
         seen = torch.ones(1, device=device)
         dist.all_reduce(seen)                      # every rank really is on the communicator
         ranks_seen = int(seen.item())
@@ -447,18 +614,18 @@ def main():
     n_steps = args.warmup + args.steps
     # rank r renders slab (step*world + r) of the frame: contiguous 4096-pixel ranges, resident in HBM
     pix = [((torch.arange(RAYS, device=device) + ((s * world + rank) * RAYS)) % total) for s in range(n_steps)]
-    gathered = torch.empty((world * RAYS, 3), device=device) if world > 1 else None
+    gathered = torch.empty((world * RAYS, 3), device=device) if dist_on else None
     torch.manual_seed(1234 + rank)
 
     def step(s):
         _, f_rgb = render_step(renderer, scene_c, scene_f, pix[s], local_rank)
-        if world > 1:
+        if dist_on:
             dist.all_gather_into_tensor(gathered, f_rgb.contiguous())   # assemble the frame slab
         return f_rgb
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -481,7 +648,7 @@ def main():
         events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     step_events.append(e_end)
     per_step = [a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:])]
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -525,11 +692,24 @@ def main():
         "config": {"workload": "Blender lego 800x800 geometry, 4096-ray batches, 64 coarse + 128 fine, fp32, "
                                "forward render through VolumeRenderer.render_scene (coarse net + fine net)",
                    "rays_per_gpu_per_step": RAYS, "global_rays_per_step": world * RAYS,
-                   "parallelism": f"ray-shard x{world}" + (" + all-gather" if world > 1 else "")},
+                   "parallelism": f"ray-shard x{world}" + (" + all-gather" if dist_on else "")},
         "rccl_ranks_seen": ranks_seen,
-        "backend": args.backend if world > 1 else None,
+        "backend": args.backend if dist_on else None,
         "roofline": roofline,
     }
+    # With a process group up the headline line leaves NOW: a secondary leg that hangs in a collective (or a rank
+    # that dies in one) can then no longer erase the measurement.  The enriched line printed after the legs repeats
+    # every key of this one -- the last JSON line is the complete record.  A leg that outlives --leg-timeout ends
+    # this process with rc 3 (the process-group timeout normally fires first and surfaces as an exception / abort).
+    watchdog = None
+    if dist_on:
+        if rank == 0:
+            print(json.dumps(dict(result, partial="headline only; the secondary legs follow on the next line")),
+                  flush=True)
+        watchdog = threading.Timer(args.leg_timeout, lambda: os._exit(3))
+        watchdog.daemon = True
+        watchdog.start()
+
     # secondary legs never take the headline line down with them
     def guarded(name, fn):
         try:
@@ -538,13 +718,18 @@ def main():
             return {"error": f"{type(exc).__name__}: {exc}"[:300], "leg": name}
 
     if not args.no_frame:       # collective: every rank takes part
-        result["frame"] = guarded("frame", lambda: frame_leg(nets, cam, rank, world, device))
+        result["frame"] = guarded("frame", lambda: frame_leg(nets, cam, rank, world, device, dist_on))
     if world == 1 and not args.no_bf16:
         result["bf16"] = guarded("bf16", lambda: bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank,
                                                           args.steps, 3))
     if (world == 1 and not args.no_train) or (world > 1 and args.train):
         result["train"] = guarded("train", lambda: train_leg(renderer, scene_c, scene_f, nets, pix, device,
                                                              local_rank, max(3, args.steps // 4), 2, world))
+    if rank == 0 and world == 1 and not args.no_runner_loop and not args.no_train:
+        result["runner_loop"] = guarded("runner_loop", lambda: runner_loop_leg(device, local_rank,
+                                                                               max(3, args.steps // 4), 2))
+    if rank == 0 and world == 1 and not args.no_configs:
+        result["configs"] = guarded("configs", lambda: configs_leg(nets, flats, device))
     if rank == 0 and world == 1 and not args.no_stages:
         result["hbm_stages"] = guarded("hbm_stages", lambda: hbm_stages(device))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -559,7 +744,9 @@ def main():
             result["cpu_baseline"] = out
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if watchdog is not None:
+        watchdog.cancel()
+    if dist_on:
         dist.destroy_process_group()
 
 

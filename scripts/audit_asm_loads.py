@@ -3,7 +3,10 @@
 
 For every inline-asm `ds_read_b128 v[a:b], ...` (between ;;#ASMSTART / ;;#ASMEND) check that no
 instruction READS or WRITES a register of v[a:b] before a later `s_waitcnt lgkmcnt(N)` that covers
-the load (N small enough given the hand-issued reads issued after it).  Usage:
+the load (N small enough given the hand-issued reads issued after it).
+For every inline-asm `global_store_dwordx4 vaddr, v[a:b], ...` check the hazard hipcc's recognizer cannot see
+inside asm: a store of more than 64 bits needs 2 wait states before a VALU instruction overwrites its data
+registers (gfx940+ "VMEM store more than 64 bits followed by a VALU write of vdata").  Usage:
     hipcc ... -save-temps -c kernel.hip ;  python scripts/audit_asm_loads.py kernel-hip-amdgcn-*.s
 """
 import re
@@ -22,8 +25,10 @@ def audit(path):
     lines = open(path).read().splitlines()
     in_asm = False
     pending = []  # [regset, line_no, younger_asm_reads]
+    stores = []   # [data regset, line_no, wait states seen since the store]
     problems = 0
     total = 0
+    n_stores = 0
     for no, raw in enumerate(lines, 1):
         ln = raw.strip()
         if ln.startswith(";;#ASMSTART"):
@@ -36,6 +41,21 @@ def audit(path):
             continue
         op, _, rest = ln.partition(" ")
         toks = [t.strip().rstrip(",") for t in re.split(r"[ ,]+", rest) if t.strip()]
+        # ---- wide-store data hazard: 2 wait states before a VALU write of the stored registers
+        if stores:
+            if op.startswith("v_") and toks:
+                for st in stores:
+                    if regs(toks[0]) & st[0]:
+                        problems += 1
+                        print(f"{path}:{no}: `{ln[:70]}` overwrites the data of the asm-issued store at line {st[1]} "
+                              f"after {st[2]} wait state(s) (needs 2)")
+            m_nop = re.fullmatch(r"s_nop (\d+)", ln)
+            for st in stores:
+                st[2] += int(m_nop.group(1)) + 1 if m_nop else 1
+            stores = [st for st in stores if st[2] < 2]
+        if in_asm and op == "global_store_dwordx4" and len(toks) >= 2:
+            stores.append([regs(toks[1]), no, 0])
+            n_stores += 1
         if not in_asm and re.search(r"\bm0\b", ln):
             # the LDS-DMA pieces overwrite M0 without restoring it: nothing the compiler emits may depend on it
             problems += 1
@@ -60,6 +80,7 @@ def audit(path):
             if touched & p[0]:
                 problems += 1
                 print(f"{path}:{no}: `{ln[:70]}` touches v{sorted(touched & p[0])} of the un-waited read at line {p[1]}")
+    print(f"{path}: {n_stores} asm-issued wide stores checked")
     print(f"{path}: {total} hand-issued LDS reads, {problems} problems")
     return problems
 

@@ -14,14 +14,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags, timeout=600):
+def _run(*flags, timeout=600, launcher=(), lines_expected=1):
+    """Run bench.py (optionally under `python -m torch.distributed.run ...`); returns the parsed JSON lines of rank 0.
+    With a process group up the bench prints the headline line first and the complete line last."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True,
-                         timeout=timeout, env=env)
+    out = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *flags], capture_output=True,
+                         text=True, timeout=timeout, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}: {out.stdout[-500:]}"
-    return json.loads(lines[0])
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == lines_expected, f"expected {lines_expected} JSON line(s) from rank 0: {out.stdout[-800:]}"
+    return lines[-1] if lines_expected == 1 else lines
 
 
 def test_self_launch_two_ranks_gloo():
@@ -43,8 +45,10 @@ def test_mismatched_launcher_world_is_refused():
 
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_full_bench():
-    line = _run("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                timeout=900)
+    first, line = _run("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                       timeout=900, lines_expected=2)
+    # the headline line leaves before any secondary (collective) leg; the last line repeats it and adds the legs
+    assert first["partial"] and "frame" not in first and first["value"] == line["value"] and "partial" not in line
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2
     assert line["value"] > 0 and line["scaling"] == "weak"
     assert line["config"]["global_rays_per_step"] == 2 * 4096
@@ -53,3 +57,21 @@ def test_two_ranks_on_one_gpu_full_bench():
     assert frame["rays"] == 640000 and frame["scaling"] == "strong"
     assert frame["equals_one_rank_image"] is True
     assert frame["image_sha256_16"] == frame["image_sha256_16_one_rank"]
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_collectives():
+    """The first RCCL calls this code ever issues must not be the driver's 8-GPU run: one rank under
+    torch.distributed.run with backend nccl (= RCCL), process group created with device_id and a timeout,
+    all_gather_into_tensor in every step, all_reduce / barrier around the timing, the frame leg's collectives."""
+    launcher = ("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                "--master-port", "29571")
+    first, line = _run("--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "3", "--warmup", "1",
+                       "--no-cpu-baseline", "--no-train", "--no-bf16", "--no-stages", "--no-configs",
+                       "--no-runner-loop", timeout=900, launcher=launcher, lines_expected=2)
+    assert first["partial"] and first["value"] > 0
+    assert line["backend"] == "nccl" and line["rccl_ranks_seen"] == 1 and line["n_gpus"] == 1
+    assert line["config"]["parallelism"].endswith("all-gather")
+    frame = line["frame"]
+    assert "error" not in frame, frame
+    assert frame["equals_one_rank_image"] is True and frame["rays"] == 640000

@@ -6,6 +6,7 @@ audit (scripts/audit_asm_loads.py) walks the emitted ISA and fails if any instru
 of a hand-issued read before a covering `s_waitcnt lgkmcnt`, or if compiler-generated code uses M0, which the
 LDS-DMA pieces overwrite without restoring."""
 import os
+import re
 import subprocess
 import sys
 
@@ -17,7 +18,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fh
          "-Wno-unused-function", "-S", "--cuda-device-only"]
 
 
-@pytest.mark.parametrize("name", ["mlp_forward", "mlp_backward", "mlp_forward_bf16"])
+@pytest.mark.parametrize("name", ["mlp_forward", "mlp_backward", "mlp_forward_bf16", "render_fused"])
 def test_hand_issued_reads_are_waited_for(name, tmp_path):
     asm = tmp_path / (name + ".s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, os.path.join(CSRC, name + ".hip"), "-o", str(asm)],
@@ -27,3 +28,6 @@ def test_hand_issued_reads_are_waited_for(name, tmp_path):
     assert out.returncode == 0, out.stdout[-2000:]
     assert "hand-issued LDS reads, 0 problems" in out.stdout
     assert int(out.stdout.rsplit(":", 1)[1].split()[0]) > 100      # the audit really saw the reads
+    # no kernel of these files may spill: a scratch reload is a VMEM load whose vmcnt wait also waits for the weight DMA
+    scratch = [int(x) for x in re.findall(r"; ScratchSize: (\d+)", asm.read_text())]
+    assert scratch and max(scratch) == 0, scratch

@@ -396,6 +396,22 @@ def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, 
             raise RuntimeError("weights must be a contiguous fp32 GPU tensor (it is updated in place)")
         u2, u3 = _gpu(u2, "u2"), _gpu(u3, "u3")
         Sf = u2.shape[1]
+    # the C ABI sees raw pointers: shapes are checked HERE (the reference fails in sample_pdf / gather on a mismatch;
+    # the kernel would read out of bounds and write the +1e-5 floor out of bounds)
+    if u1.ndim != 2 or tuple(ray_o.shape) != (n, 3) or tuple(ray_d.shape) != (n, 3):
+        raise ValueError(f"render_rays: expected ray_o, ray_d of shape ({n}, 3) for u1 {tuple(u1.shape)}; got "
+                         f"{tuple(ray_o.shape)}, {tuple(ray_d.shape)}")
+    if t_bins.numel() != Sc:
+        raise ValueError(f"render_rays: t_bins holds {t_bins.numel()} bins, u1 has {Sc} columns")
+    if weights is not None:
+        if tuple(weights.shape) != (n, Sc):
+            raise ValueError(f"render_rays: weights must be ({n}, {Sc}) like the coarse pass returned them; got "
+                             f"{tuple(weights.shape)}")
+        if tuple(u2.shape) != (n, Sf) or tuple(u3.shape) != (n, Sf):
+            raise ValueError(f"render_rays: u2, u3 must both be ({n}, {Sf}); got {tuple(u2.shape)}, {tuple(u3.shape)}")
+    if not (isinstance(packed, torch.Tensor) and packed.is_cuda and packed.is_contiguous()
+            and packed.numel() * packed.element_size() == lib.nerf_mlp_packed_bytes()):
+        raise ValueError("render_rays: `packed` is not a mlp_pack() stream of this library")
     S = Sc + Sf
     dev = u1.device
     rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)

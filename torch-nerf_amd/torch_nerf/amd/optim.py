@@ -46,7 +46,10 @@ class _Arena:
         self.n = n
         dev = self.params[0].device
         self.P = torch.empty(n, dtype=torch.float32, device=dev)
-        self.G = torch.zeros(n, dtype=torch.float32, device=dev)
+        # gradient staging; the tail of len(params) floats carries one "this rank has a gradient" flag per parameter
+        # through the data-parallel all-reduce (same collective, no second one)
+        self.G_flags = torch.zeros(n + len(self.params), dtype=torch.float32, device=dev)
+        self.G = self.G_flags[:n]
         self.M = torch.zeros(n, dtype=torch.float32, device=dev)
         self.V = torch.zeros(n, dtype=torch.float32, device=dev)
         # per-parameter step counts, like torch.optim.Adam's state["step"]; host integers between checkpoints
@@ -164,17 +167,37 @@ class FusedAdam(torch.optim.Optimizer):
                 continue          # (with world > 1 a rank without gradients still joins the all-reduce, with zeros)
             b1, b2 = group["betas"]
             if world > 1:
-                # every rank contributes its shard's gradient; a parameter without one contributes zeros,
-                # and all parameters step together
-                for _, _, a, b, g in runs:
+                # every rank contributes its shard's gradient; a parameter without one contributes zeros and a 0
+                # flag.  A parameter steps iff SOME rank has a gradient for it (what DDP + torch.optim.Adam do:
+                # no gradient anywhere -> no update, no step count).  A rank that holds every gradient itself
+                # knows the answer without looking; only a rank with a hole reads the reduced flags back (one
+                # device->host copy, on the rare ragged-shard step).
+                n_par = len(arena.params)
+                local = [True] * n_par
+                for first, last, a, b, g in runs:
                     if g is None:
                         arena.G[a:b].zero_()
+                        local[first:last] = [False] * (last - first)
                     else:
                         arena.G[a:b].copy_(g)
-                dist.all_reduce(arena.G, op=dist.ReduceOp.SUM, group=self._process_group)
-                arena.steps = [max(arena.steps) + 1] * len(arena.steps)
-                ops.adam_step(arena.P, arena.G, arena.M, arena.V, arena.steps[0], group["lr"], b1, b2,
-                              group["eps"], grad_scale=1.0 / world)
+                arena.G_flags[arena.n:].copy_(torch.tensor([float(x) for x in local]), non_blocking=False)
+                dist.all_reduce(arena.G_flags, op=dist.ReduceOp.SUM, group=self._process_group)
+                has = local if all(local) else [x > 0.0 for x in arena.G_flags[arena.n:].tolist()]
+                i = 0
+                while i < n_par:      # maximal ranges of stepping parameters with equal step counts: normally ONE
+                    if not has[i]:
+                        i += 1
+                        continue
+                    j = i + 1
+                    while j < n_par and has[j] and arena.steps[j] == arena.steps[i]:
+                        j += 1
+                    a = arena.offsets[i]
+                    b = arena.offsets[j] if j < n_par else arena.n
+                    t = arena.steps[i] + 1
+                    arena.steps[i:j] = [t] * (j - i)
+                    ops.adam_step(arena.P[a:b], arena.G[a:b], arena.M[a:b], arena.V[a:b], t, group["lr"], b1, b2,
+                                  group["eps"], grad_scale=1.0 / world)
+                    i = j
             else:
                 for first, last, a, b, g in runs:
                     if g is None:

@@ -56,6 +56,8 @@ def counter_uniform(seed: int, stream: int, first: int, count: int, device) -> t
 def ray_draws(seed: int, first_ray: int, n_rays: int, n_coarse: int, n_fine: int, device):
     """(u1_coarse_pass, u1, u2, u3) for rays [first_ray, first_ray + n_rays) -- G-independent."""
     def block(stream, width):
+        if width == 0:
+            return torch.empty((n_rays, 0), dtype=torch.float32, device=device)
         return counter_uniform(seed, stream, first_ray * width, n_rays * width, device).view(n_rays, width)
     return block(0, n_coarse), block(1, n_coarse), block(2, n_fine), block(3, n_fine)
 
@@ -139,8 +141,9 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
         n = min(per_launch, hi - first)
         bundle = sampler.generate_rays_from_pixels(camera, project_to_ndc, first=first, count=n, device=device)
         u1c, u1, u2, u3 = ray_draws(seed, first, n, n_coarse, n_fine, device)
-        _, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, bf16=bf16)
-        rgb, _ = ops.render_rays(packed_f, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1, weights=w, u2=u2,
-                                 u3=u3, bf16=bf16)
+        rgb, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, bf16=bf16)
+        if n_fine > 0:     # n_fine == 0: coarse-only frame (BASELINE configs[0])
+            rgb, _ = ops.render_rays(packed_f, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1, weights=w, u2=u2,
+                                     u3=u3, bf16=bf16)
         out[first - lo: first - lo + n] = rgb
     return out if single_rank else gather_image(out, total, group)
