@@ -719,6 +719,8 @@ def main():
 
     if not args.no_frame:       # collective: every rank takes part
         result["frame"] = guarded("frame", lambda: frame_leg(nets, cam, rank, world, device, dist_on))
+    if rank == 0 and world == 1 and not args.no_configs:     # before the train leg: that one UPDATES the networks
+        result["configs"] = guarded("configs", lambda: configs_leg(nets, flats, device))
     if world == 1 and not args.no_bf16:
         result["bf16"] = guarded("bf16", lambda: bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank,
                                                           args.steps, 3))
@@ -728,8 +730,6 @@ def main():
     if rank == 0 and world == 1 and not args.no_runner_loop and not args.no_train:
         result["runner_loop"] = guarded("runner_loop", lambda: runner_loop_leg(device, local_rank,
                                                                                max(3, args.steps // 4), 2))
-    if rank == 0 and world == 1 and not args.no_configs:
-        result["configs"] = guarded("configs", lambda: configs_leg(nets, flats, device))
     if rank == 0 and world == 1 and not args.no_stages:
         result["hbm_stages"] = guarded("hbm_stages", lambda: hbm_stages(device))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

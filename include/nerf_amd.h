@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 1
+#define NERF_AMD_ABI_VERSION 2
 
 enum {
     NERF_OK = 0,
@@ -85,47 +85,92 @@ int nerf_posenc(const float *x, int64_t M, int C, int L, int include_input, floa
                 nerf_stream_t stream);
 
 /* ---- a10: NeRF (11 Linear layers), R/network/nerf.py:24-63, :65-121
- * Fixed architecture: pos_dim 63 (L=10), view_dir_dim 27 (L=4), feat_dim 256.
- * `params` is the flat state_dict blob: fc_in.weight (256,63), fc_in.bias, fc_1.weight,
- * ... fc_out.weight (3,128), fc_out.bias = nerf_mlp_param_count() floats.
- * nerf_mlp_pack re-tiles it into the LDS image the kernels stream
- * (nerf_mlp_packed_bytes() bytes); re-run after every parameter update. */
-int64_t nerf_mlp_param_count(void);
-int64_t nerf_mlp_packed_bytes(void);
-int nerf_mlp_pack(const float *params, void *packed, nerf_stream_t stream);
+ * The network instance every nerf_mlp_* / nerf_render_* call works on: NeRF(pos_dim, view_dir_dim, feat_dim)
+ * (nerf.py:24-63) and, for the entries that take RAW points / directions, the two
+ * PositionalEncoder(3, levels, include_input) in front of it (R/signal_encoder/positional_encoder.py:27-47) --
+ * the values the runners read from yaml (coord_encode_level, dir_encode_level, include_input:
+ * R/../runners/runner_utils.py:584-612, R/../configs/signal_encoder/positional_encoding.yaml:2-4).
+ * levels < 0: the encoder is not a PositionalEncoder the kernels know; only the pre-encoded entries work.
+ * A NULL `net` is the reference's shipped configuration {63, 27, 256, 10, 1, 4, 1}.
+ *
+ * Two kernel families, chosen by nerf_mlp_path(net):
+ *   NERF_PATH_FUSED   feat_dim == 256, pos_dim <= 64, view_dir_dim <= 32: the register-resident persistent
+ *                     kernels (nerf_mlp_pack / _forward / _backward / _forward_bf16, nerf_render_*)
+ *   NERF_PATH_LAYERED anything else: one MFMA GEMM launch per layer with activations in HBM
+ *                     (nerf_mlp_layered_*), pre-encoded inputs, also returns the input gradients
+ * `params` is always the flat state_dict blob: fc_in.weight (feat,pos_dim), fc_in.bias, fc_1.weight, ...
+ * fc_out.weight (3,feat/2), fc_out.bias = nerf_mlp_param_count(net) floats. */
+typedef struct nerf_net {
+    int32_t pos_dim, view_dir_dim, feat_dim;
+    int32_t pos_levels, pos_include_input;   /* PositionalEncoder in front of `pos`      (levels < 0: unknown) */
+    int32_t dir_levels, dir_include_input;   /* PositionalEncoder in front of `view_dir` (levels < 0: unknown) */
+} nerf_net_t;
+enum { NERF_PATH_FUSED = 0, NERF_PATH_LAYERED = 1 };
+int nerf_mlp_path(const nerf_net_t *net);          /* < 0: invalid description (nerf_amd_last_error) */
+int64_t nerf_mlp_param_count(const nerf_net_t *net);
+
+/* NERF_PATH_FUSED: nerf_mlp_pack re-tiles `params` into the LDS image the kernels stream
+ * (nerf_mlp_packed_bytes(net) bytes); re-run after every parameter update. */
+int64_t nerf_mlp_packed_bytes(const nerf_net_t *net);
+int nerf_mlp_pack(const nerf_net_t *net, const float *params, void *packed, nerf_stream_t stream);
 
 /* Forward of PrimitiveCube.query_points (R/scene/primitives/cube.py:39-76) fused with
  * both PositionalEncoder.encode calls and NeRF.forward:
  *   encoded == 0: pos (M,3), view_dir (M,3) raw; encoding happens in registers
  *   encoded != 0: pos (M,63), view_dir (M,27) already encoded (plain NeRF.forward)
- * sigma (M,), rgb (M,3).  `saved` = NULL for inference, or nerf_mlp_saved_bytes(M)
+ * sigma (M,), rgb (M,3).  `saved` = NULL for inference, or nerf_mlp_saved_bytes(net, M)
  * bytes that receive the activation record nerf_mlp_backward needs. */
-int64_t nerf_mlp_saved_bytes(int64_t M);
+int64_t nerf_mlp_saved_bytes(const nerf_net_t *net, int64_t M);
 /* Float offset of element (sample m, feature k) inside a plane of `width` (256 | 128 | 64 | 32) features per
  * sample of the activation record / gradient workspace ("TF" layout, csrc/mlp_layout.h): host-side, for
  * tools and tests; the record's planes are otherwise opaque. */
 int64_t nerf_mlp_plane_offset(int width, int64_t m, int k);
-int nerf_mlp_forward(const void *packed, const float *pos, const float *view_dir, int64_t M,
+int nerf_mlp_forward(const nerf_net_t *net, const void *packed, const float *pos, const float *view_dir, int64_t M,
                      int encoded, float *sigma, float *rgb, void *saved, nerf_stream_t stream);
 
 /* ---- a10, bf16 variant (BASELINE configs[2]: "bf16 MLP weights on MFMA"), inference only.
  * Weights and layer inputs are rounded to bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate); bias, ReLU,
  * the density row, fc_out and the sigmoid stay fp32.  pos, view_dir are RAW (M,3).  Parity is a PSNR
  * bound against nerf_mlp_forward, not the 1e-5 bound.  Same `params` blob as nerf_mlp_pack. */
-int64_t nerf_mlp_packed_bf16_bytes(void);
-int nerf_mlp_pack_bf16(const float *params, void *packed_bf16, nerf_stream_t stream);
-int nerf_mlp_forward_bf16(const void *packed_bf16, const float *pos, const float *view_dir, int64_t M,
+int64_t nerf_mlp_packed_bf16_bytes(const nerf_net_t *net);
+int nerf_mlp_pack_bf16(const nerf_net_t *net, const float *params, void *packed_bf16, nerf_stream_t stream);
+int nerf_mlp_forward_bf16(const nerf_net_t *net, const void *packed_bf16, const float *pos, const float *view_dir, int64_t M,
                           float *sigma, float *rgb, nerf_stream_t stream);
 
 /* ---- a13 (MLP part): gradients of all 22 parameter tensors (autograd in the
  * reference, entered at runners/train.py:215).  g_params (param_count floats, same
- * layout as `params`) is OVERWRITTEN.  workspace: nerf_mlp_backward_workspace_bytes(M). */
-int64_t nerf_mlp_backward_workspace_bytes(int64_t M);
-int nerf_mlp_backward(const void *packed, const float *params, const float *pos,
+ * layout as `params`) is OVERWRITTEN.  workspace: nerf_mlp_backward_workspace_bytes(net, M). */
+int64_t nerf_mlp_backward_workspace_bytes(const nerf_net_t *net, int64_t M);
+int nerf_mlp_backward(const nerf_net_t *net, const void *packed, const float *params, const float *pos,
                       const float *view_dir, int64_t M, int encoded, const float *sigma,
                       const float *rgb, const void *saved, const float *g_sigma,
                       const float *g_rgb, float *g_params, void *workspace,
                       nerf_stream_t stream);
+
+/* ---- a10 + a13, NERF_PATH_LAYERED (any pos_dim / view_dir_dim / feat_dim): NeRF.forward on PRE-ENCODED inputs
+ * pos (M,pos_dim), view_dir (M,view_dir_dim) as one fp32-MFMA GEMM launch per layer (bias, ReLU, sigmoid and the
+ * two torch.cat of nerf.py:108,:116 fused into the GEMMs), activations in `record`:
+ *   record_rows >= M : the whole batch is recorded (what nerf_mlp_layered_backward needs)
+ *   record_rows <  M : inference, the batch is walked in chunks of record_rows rows through the same buffer
+ * record = nerf_mlp_layered_record_bytes(net, record_rows) bytes.
+ * Backward = autograd's result for nerf.py:102-119: g_params (OVERWRITTEN, layout of `params`) and, when non-NULL,
+ * g_pos (M,pos_dim) / g_view_dir (M,view_dir_dim), the gradients w.r.t. the encoded inputs.  No atomics: the
+ * sample-axis reductions are split into fixed slices summed in a fixed order (bit-reproducible gradients).
+ * workspace: nerf_mlp_layered_workspace_bytes(net, M). */
+int64_t nerf_mlp_layered_record_bytes(const nerf_net_t *net, int64_t rows);
+int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t M);
+int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params, const float *pos, const float *view_dir,
+                             int64_t M, float *sigma, float *rgb, void *record, int64_t record_rows,
+                             nerf_stream_t stream);
+int nerf_mlp_layered_backward(const nerf_net_t *net, const float *params, const float *pos, const float *view_dir,
+                              int64_t M, const float *sigma, const float *rgb, const void *record,
+                              const float *g_sigma, const float *g_rgb, float *g_params, float *g_pos,
+                              float *g_view_dir, void *workspace, nerf_stream_t stream);
+
+/* ---- a8, backward: x (M,C), g_out (M, out_dim) -> g_x (M,C) = the gradient autograd returns for `in_signal` of
+ * PositionalEncoder.encode (positional_encoder.py:84-104): g_x = [g_in] + sum_l 2^l (cos(2^l x) g_sin_l - sin(2^l x) g_cos_l). */
+int nerf_posenc_backward(const float *x, const float *g_out, int64_t M, int C, int L, int include_input,
+                         float *g_x, nerf_stream_t stream);
 
 /* ---- a11: QuadratureIntegrator.integrate_along_rays,
  * R/renderer/integrators/quadrature_integrator.py:14-67
@@ -154,11 +199,11 @@ int nerf_composite_backward(const float *sigma, const float *radiance, const flo
  * positions -- for parity checks of the fused kernel (both NULL: identical to nerf_render_rays). */
 int nerf_render_is_fused(int Sc, int Sf, int fine);
 int64_t nerf_render_workspace_bytes(int64_t n, int S);
-int nerf_render_rays(const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc,
+int nerf_render_rays(const nerf_net_t *net, const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc,
                      int Sf, const float *t_bins, float partition_size, float *weights_in,
                      const float *u1, const float *u2, const float *u3, float *rgb,
                      float *weights_out, void *workspace, nerf_stream_t stream);
-int nerf_render_pass(const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc,
+int nerf_render_pass(const nerf_net_t *net, const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc,
                      int Sf, const float *t_bins, float partition_size, float *weights_in,
                      const float *u1, const float *u2, const float *u3, float *rgb,
                      float *weights_out, int64_t *bin_idx, float *t, void *workspace, nerf_stream_t stream);

@@ -14,10 +14,10 @@ pts = torch.rand(M, 3, device="cuda") * 8 - 4
 dirs = torch.rand(M, 3, device="cuda") * 2 - 1
 sigma = torch.empty(M, device="cuda")
 rgb = torch.zeros(3 * M + 65536, device="cuda")          # stamps land behind the 3 M colours
-saved = torch.empty(lib.nerf_mlp_saved_bytes(M) // 4, device="cuda") if save else None
+saved = torch.empty(lib.nerf_mlp_saved_bytes(None, M) // 4, device="cuda") if save else None
 for _ in range(3):
     rgb[3 * M:].zero_()
-    rc = lib.nerf_mlp_forward(packed.data_ptr(), pts.data_ptr(), dirs.data_ptr(), M, 0, sigma.data_ptr(), rgb.data_ptr(),
+    rc = lib.nerf_mlp_forward(None, packed.data_ptr(), pts.data_ptr(), dirs.data_ptr(), M, 0, sigma.data_ptr(), rgb.data_ptr(),
                               saved.data_ptr() if save else None, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()

@@ -15,7 +15,7 @@ sigma = torch.empty(M, device="cuda")
 rgb = torch.zeros(3 * M + 65536, device="cuda")        # stamps land behind the 3 M colours
 for _ in range(3):
     rgb[3 * M:].zero_()
-    lib.nerf_mlp_forward_bf16(packed.data_ptr(), pts.data_ptr(), dirs.data_ptr(), M, sigma.data_ptr(), rgb.data_ptr(),
+    lib.nerf_mlp_forward_bf16(None, packed.data_ptr(), pts.data_ptr(), dirs.data_ptr(), M, sigma.data_ptr(), rgb.data_ptr(),
                               torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
 t = rgb[3 * M:].view(torch.int64).cpu().numpy()

@@ -12,11 +12,11 @@ pts = torch.rand(M, 3, device="cuda") * 8 - 4
 dirs = torch.rand(M, 3, device="cuda") * 2 - 1
 gs = torch.randn(M, device="cuda"); gc = torch.randn(M, 3, device="cuda")
 sigma, rgb, saved = ops.mlp_forward(packed, pts, dirs, False, save=True)
-ws = torch.zeros(lib.nerf_mlp_backward_workspace_bytes(M) // 4, device="cuda")
-g = torch.empty(lib.nerf_mlp_param_count(), device="cuda")
+ws = torch.zeros(lib.nerf_mlp_backward_workspace_bytes(None, M) // 4, device="cuda")
+g = torch.empty(lib.nerf_mlp_param_count(None), device="cuda")
 for _ in range(2):
     ws.zero_()
-    rc = lib.nerf_mlp_backward(packed.data_ptr(), flat.data_ptr(), pts.data_ptr(), dirs.data_ptr(), M, 0, sigma.data_ptr(),
+    rc = lib.nerf_mlp_backward(None, packed.data_ptr(), flat.data_ptr(), pts.data_ptr(), dirs.data_ptr(), M, 0, sigma.data_ptr(),
                                rgb.data_ptr(), saved.data_ptr(), gs.data_ptr(), gc.data_ptr(), g.data_ptr(), ws.data_ptr(),
                                torch.cuda.current_stream().cuda_stream)
     assert rc == 0

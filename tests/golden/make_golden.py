@@ -430,9 +430,53 @@ def f10_llff_poses():
                                                   np.array([1.0, 2.0, 3.0])))
 
 
+# ---------------------------------------------------------------- F11 network / encoder variants
+NET_VARIANTS = {   # tag: (coord_encode_level, dir_encode_level, include_input, feat_dim) -- the knobs of
+    # configs/signal_encoder/positional_encoding.yaml:2-4 and NeRF's feat_dim (network/nerf.py:27)
+    "l6_l2": (6, 2, True, 256),
+    "l4_l4": (4, 4, True, 256),
+    "l10_l4_noinput": (10, 4, False, 256),
+    "l10_l4_f128": (10, 4, True, 128),
+    "l12_l6_f64": (12, 6, True, 64),      # pos_dim 75 > 64, view_dir_dim 39 > 32
+}
+
+
+def f11_net_variants():
+    """NeRF(coord_enc.out_dim, dir_enc.out_dim[, feat_dim]) as runner_utils.py:584-612 builds it for other yaml
+    values: outputs, parameter-gradient digests and the gradients autograd returns for the encoded inputs."""
+    rng = np.random.RandomState(23)
+    M = 96
+    pts = rng.uniform(-3, 3, (M, 3)).astype(np.float32)
+    dirs = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    g_sigma = rng.standard_normal(M).astype(np.float32)
+    g_rgb = rng.standard_normal((M, 3)).astype(np.float32)
+    out = dict(pts=pts, dirs=dirs, g_sigma=g_sigma, g_rgb=g_rgb)
+    for tag, (lp, ld, inc, feat) in NET_VARIANTS.items():
+        ce, de_ = RefPE(3, lp, inc), RefPE(3, ld, inc)
+        pts_t = torch.from_numpy(pts.copy()).requires_grad_(True)     # leaves: autograd runs back through encode()
+        dirs_t = torch.from_numpy(dirs.copy()).requires_grad_(True)
+        pe, de = ce.encode(pts_t), de_.encode(dirs_t)
+        pe.retain_grad(); de.retain_grad()
+        flat = synth.nerf_flat_params(seed=5, pos_dim=ce.out_dim, view_dir_dim=de_.out_dim, feat_dim=feat,
+                                      sigma_bias=0.5, sigma_gain=4.0)
+        net = ref_nerf.NeRF(ce.out_dim, de_.out_dim, feat)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in
+                             synth.split_flat_params(flat, ce.out_dim, de_.out_dim, feat).items()})
+        sigma, rgb = net(pe, de)
+        (sigma * torch.from_numpy(g_sigma)).sum().add((rgb * torch.from_numpy(g_rgb)).sum()).backward()
+        out[tag + "_dims"] = np.array([ce.out_dim, de_.out_dim, feat, lp, ld, int(inc)])
+        out[tag + "_pe"] = pe.detach().numpy(); out[tag + "_de"] = de.detach().numpy()
+        out[tag + "_sigma"] = sigma.detach().numpy(); out[tag + "_rgb"] = rgb.detach().numpy()
+        out[tag + "_g_pe"] = pe.grad.numpy(); out[tag + "_g_de"] = de.grad.numpy()
+        out[tag + "_g_pts"] = pts_t.grad.numpy(); out[tag + "_g_dirs"] = dirs_t.grad.numpy()
+        for k, v in grad_digest(net).items():
+            out[tag + "_grad_" + k] = v
+    save("f11_net_variants", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    every = dict(f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
+    every = dict(f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
                  f8=f8_adam)
     for name in (sys.argv[1:] or list(every)):      # e.g. `make_golden.py f8` rewrites one fixture
         every[name]()

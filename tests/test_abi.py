@@ -21,12 +21,41 @@ def test_library_builds_loads_and_exports_header():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nerf_amd_abi_version() == 1
-    assert lib.nerf_mlp_param_count() == 595844
+    assert lib.nerf_amd_abi_version() == 2
+    assert lib.nerf_mlp_param_count(None) == 595844
     # sizes only -- no compute without a GPU
-    assert lib.nerf_mlp_packed_bytes() == 13312 + (78 + 68) * 32768
-    assert lib.nerf_mlp_saved_bytes(128) == 128 * (2528 * 4 + 9 * 32)
-    assert lib.nerf_mlp_saved_bytes(129) == 256 * (2528 * 4 + 9 * 32)  # rows padded to 128
+    assert lib.nerf_mlp_packed_bytes(None) == 13312 + (78 + 68) * 32768
+    assert lib.nerf_mlp_saved_bytes(None, 128) == 128 * (2528 * 4 + 9 * 32)
+    assert lib.nerf_mlp_saved_bytes(None, 129) == 256 * (2528 * 4 + 9 * 32)  # rows padded to 128
+
+
+def test_network_descriptions_choose_the_kernel_family():
+    """nerf_net_t -> nerf_mlp_path: the reference's constructor space NeRF(pos_dim, view_dir_dim, feat_dim)
+    (network/nerf.py:24-63) and the yaml knobs in front of it (runner_utils.py:584-612).  Host logic only."""
+    import ctypes
+    from torch_nerf.amd import synth
+    lib = _lib.load()
+
+    def net(*v):
+        return ctypes.byref(_lib.NetStruct(*v))
+
+    assert lib.nerf_mlp_path(None) == _lib.PATH_FUSED
+    for lp, ld, inc, feat, path in [(10, 4, 1, 256, 0), (6, 2, 1, 256, 0), (4, 4, 1, 256, 0), (10, 4, 0, 256, 0),
+                                    (10, 4, 1, 128, 1), (12, 6, 1, 64, 1), (11, 4, 1, 256, 1), (10, 5, 0, 256, 0),
+                                    (10, 5, 1, 256, 1)]:
+        e_p, e_d = 6 * lp + 3 * inc, 6 * ld + 3 * inc
+        n = net(e_p, e_d, feat, lp, inc, ld, inc)
+        assert lib.nerf_mlp_path(n) == path, (lp, ld, inc, feat)
+        assert lib.nerf_mlp_param_count(n) == synth.param_count(e_p, e_d, feat)
+        assert (lib.nerf_mlp_packed_bytes(n) > 0) == (path == 0)      # the layered family streams `params` as they are
+        assert lib.nerf_mlp_layered_record_bytes(n, 10) == 40 * (8 * feat + feat + 1 + feat // 2)
+        assert lib.nerf_mlp_layered_workspace_bytes(n, 1000) > 0
+    # encoders the kernels do not know (levels < 0): any widths, pre-encoded entries only
+    assert lib.nerf_mlp_path(net(16, 16, 256, -1, 0, -1, 0)) == 0          # e.g. SHEncoder(3, 4) on both inputs
+    assert lib.nerf_mlp_path(net(100, 16, 256, -1, 0, -1, 0)) == 1
+    # a description that contradicts itself is refused
+    assert lib.nerf_mlp_path(net(63, 27, 256, 9, 1, 4, 1)) < 0 and b"levels" in lib.nerf_amd_last_error()
+    assert lib.nerf_mlp_path(net(0, 27, 256, -1, 0, -1, 0)) < 0
 
 
 def test_plane_layout_is_a_bijection_with_coalesced_stores_and_conflict_free_fragments():

@@ -31,7 +31,7 @@ def test_error_codes_instead_of_crashes():
     assert lib.nerf_composite_forward(None, None, None, 4, 64, None, None, st) == 1       # NERF_ERR_ARG
     assert b"null" in lib.nerf_amd_last_error()
     assert lib.nerf_sample_stratified(None, None, -1, 64, None, 0.1, None, None, None, None, None, st) == 1
-    assert lib.nerf_mlp_forward(None, None, None, 10, 0, None, None, None, st) == 1
+    assert lib.nerf_mlp_forward(None, None, None, None, 10, 0, None, None, None, st) == 1
     x = torch.zeros(8, device="cuda")
     big = 20000  # more samples per ray than the LDS row buffer holds
     assert lib.nerf_sample_stratified(x.data_ptr(), x.data_ptr(), 1, big, x.data_ptr(), 0.1, x.data_ptr(), None,

@@ -113,8 +113,13 @@ def test_nerf_module_layout_and_errors():
         net(torch.ones(4, 60), torch.ones(4, 27))
     with pytest.raises(ValueError):
         net(torch.ones(4, 63), torch.ones(4, 24))
-    with pytest.raises(NotImplementedError):
-        network.NeRF(60, 24, 128)(torch.ones(2, 60), torch.ones(2, 24))
+    # every NeRF(pos_dim, view_dir_dim, feat_dim) the reference's constructor accepts (nerf.py:24-63) is built and
+    # mapped to a kernel family; on a box without a GPU the call itself refuses (no CPU fallback)
+    other = network.NeRF(60, 24, 128)
+    assert sum(p.numel() for p in other.parameters()) == synth.param_count(60, 24, 128)
+    assert not other._net.fused and network.NeRF(39, 15)._net.fused and not network.NeRF(75, 27)._net.fused
+    with pytest.raises(RuntimeError, match="GPU"):
+        other(torch.ones(2, 60), torch.ones(2, 24))
 
 
 def test_positional_encoder_dims():
@@ -129,8 +134,20 @@ def test_primitive_cube_contract():
     net = network.NeRF(63, 27)
     cube = scene.PrimitiveCube(net, enc)
     assert cube.radiance_field is net and cube.encoders is enc and cube.fused_query
+    assert cube.fused_net().is_shipped
+    # encoders whose widths do not match the network: no fused query (the step-by-step path then raises like the reference)
     assert not scene.PrimitiveCube(net, {"coord_enc": PositionalEncoder(3, 8, True),
                                          "dir_enc": PositionalEncoder(3, 4, True)}).fused_query
+    # other yaml values (runner_utils.py:584-612): fused as long as the widths fit two / one 32-wide blocks and feat is 256
+    e62 = {"coord_enc": PositionalEncoder(3, 6, True), "dir_enc": PositionalEncoder(3, 2, True)}
+    spec = scene.PrimitiveCube(network.NeRF(39, 15), e62).fused_net()
+    assert spec is not None and spec.key == (39, 15, 256, 6, 1, 2, 1) and not spec.is_shipped
+    eno = {"coord_enc": PositionalEncoder(3, 10, False), "dir_enc": PositionalEncoder(3, 4, False)}
+    assert scene.PrimitiveCube(network.NeRF(60, 24), eno).fused_net().key == (60, 24, 256, 10, 0, 4, 0)
+    assert network.NeRF(60, 24).inferred_net().key == (60, 24, 256, 10, 0, 4, 0)
+    assert not scene.PrimitiveCube(network.NeRF(63, 27, 128), enc).fused_query          # layered family
+    e126 = {"coord_enc": PositionalEncoder(3, 12, True), "dir_enc": PositionalEncoder(3, 6, True)}
+    assert not scene.PrimitiveCube(network.NeRF(75, 39), e126).fused_query             # too wide for the fused kernels
     with pytest.raises(ValueError):
         scene.PrimitiveCube("not a module", enc)
     with pytest.raises(ValueError):

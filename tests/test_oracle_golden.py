@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from torch_nerf.amd import synth
-from helpers import check_grad_digest
+from helpers import NET_VARIANTS, check_grad_digest, variant_params
 
 
 def _bits(a):
@@ -92,6 +92,26 @@ def test_mlp_forward_backward(golden, oracle, tag):
     np.testing.assert_allclose(rgb, g[tag + "_rgb"], rtol=0, atol=1e-5)
     grad = oracle.mlp_backward(flat, pe, de, g[tag + "_g_sigma"], g[tag + "_g_rgb"])
     check_grad_digest(grad, g, tag + "_grad_", rtol=2e-4, atol_scale=2e-3)
+
+
+@pytest.mark.parametrize("tag", sorted(NET_VARIANTS))
+def test_mlp_variants(golden, oracle, tag):
+    """F11: the network built from other yaml values (encode levels, include_input) and other feat_dim
+    (runner_utils.py:584-612, nerf.py:24-63): outputs, parameter gradients, and the gradients w.r.t. the encoded inputs."""
+    g = golden("f11_net_variants")
+    lp, ld, inc, feat = NET_VARIANTS[tag]
+    flat, dims = variant_params(g, tag)
+    pe = oracle.posenc(g["pts"], lp, include_input=inc)
+    de = oracle.posenc(g["dirs"], ld, include_input=inc)
+    assert pe.shape[1] == dims[0] and de.shape[1] == dims[1]
+    np.testing.assert_allclose(pe, g[tag + "_pe"], rtol=0, atol=3e-7)
+    sigma, rgb = oracle.mlp_forward(flat, g[tag + "_pe"], g[tag + "_de"], F=feat)
+    np.testing.assert_allclose(sigma, g[tag + "_sigma"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(rgb, g[tag + "_rgb"], rtol=0, atol=1e-5)
+    grad, g_pe, g_de, _ = oracle.mlp_backward_ex(flat, g[tag + "_pe"], g[tag + "_de"], g["g_sigma"], g["g_rgb"], F=feat)
+    check_grad_digest(grad, g, tag + "_grad_", rtol=2e-4, atol_scale=2e-3, dims=dims)
+    for got, want in ((g_pe, g[tag + "_g_pe"]), (g_de, g[tag + "_g_de"])):
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5 * np.abs(want).max())
 
 
 @pytest.mark.parametrize("S", [64, 192, 7])

@@ -1,4 +1,4 @@
-// a13 (MLP part): gradients of the 22 parameter tensors of NeRF(63, 27, 256).
+// a13 (MLP part): gradients of the 22 parameter tensors of NeRF(pos_dim <= 64, view_dir_dim <= 32, 256).
 //
 // The reference obtains them from autograd (entered at runners/train.py:215, per layer
 // mm x2 + threshold_backward + sum).  Here the reverse pass is three hand-written stages:
@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "mlp_device.h"
+#include "net.h"
 
 namespace {
 
@@ -232,6 +233,7 @@ struct GemmTable {
     GemmDesc g[MAX_GEMMS];
     int n;
     int64_t work_total;           // sum over items of tiles * cost
+    int64_t off_b8, off_wout, off_bout;   // flat-gradient offsets of fc_8.bias, fc_out.weight, fc_out.bias
 };
 
 __device__ __forceinline__ int64_t slice_stride(const GemmDesc &g) {
@@ -560,7 +562,7 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
         if (threadIdx.x < 4) {
             float t = 0.0f;
             for (int q = 0; q < 64; ++q) t += part[q][threadIdx.x];
-            g_params[threadIdx.x < 3 ? b_offset(10) + threadIdx.x : b_offset(8)] = t;   // fc_out.bias[0..2], fc_8.bias[0]
+            g_params[threadIdx.x < 3 ? table.off_bout + threadIdx.x : table.off_b8] = t;   // fc_out.bias[0..2], fc_8.bias[0]
         }
         return;
     }
@@ -583,7 +585,7 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
         } else {   // side-job rows: density row of fc_8 = weight[0, :]; fc_out.weight (3 x 128, contiguous)
             const int k = (int)(e - with_bias);
             src = (int64_t)g.a_width * g.x_width + 256 + k;
-            dst = (g.flags & FLAG_DENSITY) ? g.w_off + k : w_offset(10) + k;
+            dst = (g.flags & FLAG_DENSITY) ? g.w_off + k : table.off_wout + k;
         }
         float s = 0.0f;
         for (int sl = 0; sl < g.num_slices; ++sl) s += base[sl * stride + src];
@@ -600,7 +602,8 @@ struct Plan {
     int64_t partial_floats;
 };
 
-Plan make_plan(int64_t M, int cus) {
+Plan make_plan(const Net &net, int64_t M, int cus) {
+    const int E_POS = net.e_pos, E_DIR = net.e_dir;
     const int64_t MP = padded_rows(M);
     const int64_t tiles = MP / 32;
     Plan p;
@@ -610,8 +613,8 @@ Plan make_plan(int64_t M, int cus) {
                    int row0, int flags) {
         GemmDesc &g = T.g[n++];
         g.a_off = a_off; g.x_off = x_off; g.a_width = a_width; g.x_width = x_width;
-        g.flags = flags; g.in_features = DIMS[layer].in; g.col0 = col0; g.valid_cols = valid_cols; g.row0 = row0;
-        g.w_off = w_offset(layer); g.b_off = b_offset(layer);
+        g.flags = flags; g.in_features = net.layer_in(layer); g.col0 = col0; g.valid_cols = valid_cols; g.row0 = row0;
+        g.w_off = net.w_offset(layer); g.b_off = net.b_offset(layer);
     };
     add(0, dy_plane(MP, 0), 256, pl_pe(MP), 64, 0, E_POS, 0, FLAG_BIAS);
     for (int l = 1; l <= 4; ++l) add(l, dy_plane(MP, l), 256, pl_h(MP, l - 1), 256, 0, 256, 0, FLAG_BIAS);
@@ -623,6 +626,7 @@ Plan make_plan(int64_t M, int cus) {
     add(9, dy9_plane(MP), 128, pl_y8(MP), 256, 0, 256, 0, FLAG_BIAS | FLAG_FCOUT);
     add(9, dy9_plane(MP), 128, pl_de(MP), 32, FEAT, E_DIR, 0, 0);
     T.n = n;
+    T.off_b8 = net.b_offset(8); T.off_wout = net.w_offset(10); T.off_bout = net.b_offset(10);
     // Relative time of one 32-row tile per item shape (measured on MI355X with all CUs busy, ns; scripts/dw_timing.py):
     // wide tiles are MFMA-bound (256 MFMAs per wave, 6.83 us at the peak), the thin ones lean on the DMA round trip.
     // The fc_8 item carries the density row (+1.4 %).
@@ -661,7 +665,9 @@ inline int64_t align256f(int64_t floats) { return (floats + 63) & ~(int64_t)63; 
 
 }  // namespace
 
-NERF_API int64_t nerf_mlp_backward_workspace_bytes(int64_t M) {
+NERF_API int64_t nerf_mlp_backward_workspace_bytes(const nerf_net_t *net, int64_t M) {
+    mlp::Net n;
+    if (nerf::fused_net(net, n, "nerf_mlp_backward_workspace_bytes") != NERF_OK) return -1;
     if (M <= 0) return 0;
     const int64_t MP = mlp::padded_rows(M);
     // upper bound on the partial buffer that does not depend on the device: 2 x 256 slices of a full tile
@@ -669,16 +675,18 @@ NERF_API int64_t nerf_mlp_backward_workspace_bytes(int64_t M) {
     return 4 * (align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE) + partial + (int64_t)BIAS_PARTIAL_FLOATS);
 }
 
-NERF_API int nerf_mlp_backward(const void *packed, const float *params, const float *pos,
+NERF_API int nerf_mlp_backward(const nerf_net_t *net_abi, const void *packed, const float *params, const float *pos,
                                const float *view_dir, int64_t M, int encoded, const float *sigma,
                                const float *rgb, const void *saved, const float *g_sigma, const float *g_rgb,
                                float *g_params, void *workspace, nerf_stream_t stream) {
     (void)params; (void)pos; (void)view_dir; (void)encoded;  // the saved record holds the encodings
+    mlp::Net net;
+    if (int rc = nerf::fused_net(net_abi, net, "nerf_mlp_backward")) return rc;
     NERF_REQUIRE(M >= 0, "nerf_mlp_backward: negative M");
     NERF_REQUIRE(g_params, "nerf_mlp_backward: null g_params");
     hipStream_t s = nerf::as_stream(stream);
     if (M == 0) {
-        if (hipMemsetAsync(g_params, 0, sizeof(float) * mlp::PARAM_COUNT, s) != hipSuccess)
+        if (hipMemsetAsync(g_params, 0, sizeof(float) * net.param_count(), s) != hipSuccess)
             return nerf::check_launch("nerf_mlp_backward: memset");
         return NERF_OK;
     }
@@ -695,7 +703,7 @@ NERF_API int nerf_mlp_backward(const void *packed, const float *params, const fl
     const int64_t MP = mlp::padded_rows(M);
     float *dy = static_cast<float *>(workspace);
     float *partial = dy + align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE);
-    const Plan plan = make_plan(M, cus);
+    const Plan plan = make_plan(net, M, cus);
     float *bias_partial = partial + plan.partial_floats;
     const float *sv = static_cast<const float *>(saved);
 

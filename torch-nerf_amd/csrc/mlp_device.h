@@ -37,19 +37,20 @@ __device__ __forceinline__ void sincos_cw(float x, float &s, float &c) {
     c = ((q + 1) & 2) ? -cc : cc;
 }
 
-// feature k of PositionalEncoder(3, L, include_input=True).encode((x,y,z)); 0 beyond kmax
-// layout (positional_encoder.py:83-88): [x y z | sin(2^0 xyz) cos(2^0 xyz) | sin(2^1 xyz) ...]
+// feature k of PositionalEncoder(3, L, include_input).encode((x,y,z)); 0 beyond kmax = its out_dim
+// layout (positional_encoder.py:83-88): [x y z (if include_input) | sin(2^0 xyz) cos(2^0 xyz) | sin(2^1 xyz) ...]
 template <bool EXACT>
-__device__ __forceinline__ float enc_feature(int k, float x, float y, float z, int kmax) {
-    const int e = k - 3;
-    const int f = e / 6;
+__device__ __forceinline__ float enc_feature(int k, float x, float y, float z, int kmax, int include_input = 1) {
+    const int raw = include_input ? 3 : 0;
+    const int e = k - raw;
+    const int f = e < 0 ? 0 : e / 6;
     const int r6 = e - 6 * f;
-    const int ch = k < 3 ? k : (r6 >= 3 ? r6 - 3 : r6);
+    const int ch = k < raw ? k : (r6 >= 3 ? r6 - 3 : r6);
     const float v = ch == 0 ? x : (ch == 1 ? y : z);
     float s, c;
-    sincos_cw<EXACT>(ldexpf(v, f < 0 ? 0 : f), s, c);
+    sincos_cw<EXACT>(ldexpf(v, f), s, c);
     const float t = r6 >= 3 ? c : s;
-    return k < 3 ? v : (k < kmax ? t : 0.0f);
+    return k < raw ? v : (k < kmax ? t : 0.0f);
 }
 
 // All NF (64 | 32) encoding features of one sample, tail beyond 3 + 6 LEVELS zero: ONE sincos per (octave, channel)
@@ -87,10 +88,10 @@ __device__ __forceinline__ void table_to_fragment(const float (&F)[NF], int blk,
 }
 
 // largest |argument| the encodings of this sample will see: 2^(L-1) * max|coordinate|
-__device__ __forceinline__ bool encoding_needs_exact(const float (&raw)[6]) {
+__device__ __forceinline__ bool encoding_needs_exact(const float (&raw)[6], int l_pos, int l_dir) {
     const float p = fmaxf(fmaxf(fabsf(raw[0]), fabsf(raw[1])), fabsf(raw[2]));
     const float d = fmaxf(fmaxf(fabsf(raw[3]), fabsf(raw[4])), fabsf(raw[5]));
-    return !(ldexpf(p, L_POS - 1) < 30000.0f && ldexpf(d, L_DIR - 1) < 30000.0f);  // also true for NaN
+    return !(ldexpf(p, l_pos - 1) < 30000.0f && ldexpf(d, l_dir - 1) < 30000.0f);  // also true for NaN
 }
 
 // ReLU as ONE instruction.  fmaxf(x, 0) on a raw MFMA result compiles to two v_max_f32 (hipcc first

@@ -21,13 +21,14 @@
 #include "common.h"
 #include "mlp_device.h"
 #include "mlp_tile.h"
+#include "net.h"
 
 namespace {
 
 using namespace mlp;
 
-template <bool ENCODED, bool SAVE>
-__global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restrict__ packed,
+template <int INPUT, bool SAVE>
+__global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const Net net, const char *__restrict__ packed,
                                                               const float *__restrict__ pos,
                                                               const float *__restrict__ dir, int64_t M,
                                                               float *__restrict__ sigma_out,
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
     // raw inputs of the first tile; later tiles are prefetched one tile ahead
     float raw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto load_raw = [&](int64_t tile) {
-        if (ENCODED || tile >= ntiles) return;
+        if (INPUT == IN_ENCODED || tile >= ntiles) return;
         int64_t mm = tile * TILE_SAMPLES + wave * 32 + i;
         if (mm >= M) mm = M - 1;
 #pragma unroll
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
         const int64_t mc = valid ? m : M - 1;
 
         float sigma, y[3];
-        forward_tile<ENCODED, SAVE>(raw, pos, dir, mc, m, MP, h, pipe, lds, cb, offq, saved,
+        forward_tile<INPUT, SAVE>(net, raw, pos, dir, mc, m, MP, h, pipe, lds, cb, offq, saved,
                                     [&]() { load_raw(tile + gridDim.x); },  // next tile's points: a whole tile of MFMAs hides the latency
                                     tl, sigma, y);
         if (valid && h == 0) {
@@ -103,10 +104,10 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char *__restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool ENCODED, bool SAVE>
-int launch_forward(const void *packed, const float *pos, const float *dir, int64_t M, float *sigma,
+template <int INPUT, bool SAVE>
+int launch_forward(const Net &net, const void *packed, const float *pos, const float *dir, int64_t M, float *sigma,
                    float *rgb, void *saved, hipStream_t stream) {
-    auto kern = mlp_forward_kernel<ENCODED, SAVE>;
+    auto kern = mlp_forward_kernel<INPUT, SAVE>;
     static nerf::DeviceMask configured{0};  // one per template instance
     if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, configured,
                                           "nerf_mlp_forward: LDS attribute"))
@@ -114,7 +115,7 @@ int launch_forward(const void *packed, const float *pos, const float *dir, int64
     const int64_t ntiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES;
     const int cus = nerf::device_cus();
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, stream,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, stream, net,
                        reinterpret_cast<const char *>(packed), pos, dir, M, sigma, rgb,
                        reinterpret_cast<float *>(saved));
     return nerf::check_launch("nerf_mlp_forward");
@@ -127,19 +128,28 @@ NERF_API int64_t nerf_mlp_plane_offset(int width, int64_t m, int k) {
     return mlp::tf_offset(width, m, k);
 }
 
-NERF_API int64_t nerf_mlp_saved_bytes(int64_t M) {
+NERF_API int64_t nerf_mlp_saved_bytes(const nerf_net_t *net, int64_t M) {
+    mlp::Net n;
+    if (nerf::fused_net(net, n, "nerf_mlp_saved_bytes") != NERF_OK) return -1;
     return M < 0 ? 0 : mlp::padded_rows(M) * (int64_t)mlp::SAVED_BYTES_PER_SAMPLE;
 }
 
-NERF_API int nerf_mlp_forward(const void *packed, const float *pos, const float *view_dir, int64_t M,
-                              int encoded, float *sigma, float *rgb, void *saved, nerf_stream_t stream) {
+NERF_API int nerf_mlp_forward(const nerf_net_t *net_abi, const void *packed, const float *pos, const float *view_dir,
+                              int64_t M, int encoded, float *sigma, float *rgb, void *saved, nerf_stream_t stream) {
+    mlp::Net net;
+    if (int rc = nerf::fused_net(net_abi, net, "nerf_mlp_forward")) return rc;
     NERF_REQUIRE(M >= 0, "nerf_mlp_forward: negative M");
     if (M == 0) return NERF_OK;
     NERF_REQUIRE(packed && pos && view_dir && sigma && rgb, "nerf_mlp_forward: null pointer");
     hipStream_t s = nerf::as_stream(stream);
     if (encoded)
-        return saved ? launch_forward<true, true>(packed, pos, view_dir, M, sigma, rgb, saved, s)
-                     : launch_forward<true, false>(packed, pos, view_dir, M, sigma, rgb, saved, s);
-    return saved ? launch_forward<false, true>(packed, pos, view_dir, M, sigma, rgb, saved, s)
-                 : launch_forward<false, false>(packed, pos, view_dir, M, sigma, rgb, saved, s);
+        return saved ? launch_forward<IN_ENCODED, true>(net, packed, pos, view_dir, M, sigma, rgb, saved, s)
+                     : launch_forward<IN_ENCODED, false>(net, packed, pos, view_dir, M, sigma, rgb, saved, s);
+    if (!nerf::raw_inputs_ok(net))
+        return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_mlp_forward: raw inputs need both encode levels in nerf_net_t");
+    if (net.is_default())   // the reference's shipped yaml: compile-time encoding table
+        return saved ? launch_forward<IN_SHIPPED, true>(net, packed, pos, view_dir, M, sigma, rgb, saved, s)
+                     : launch_forward<IN_SHIPPED, false>(net, packed, pos, view_dir, M, sigma, rgb, saved, s);
+    return saved ? launch_forward<IN_LEVELS, true>(net, packed, pos, view_dir, M, sigma, rgb, saved, s)
+                 : launch_forward<IN_LEVELS, false>(net, packed, pos, view_dir, M, sigma, rgb, saved, s);
 }

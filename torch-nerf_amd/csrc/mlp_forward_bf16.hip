@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "mlp_device.h"
+#include "net.h"
 
 namespace {
 
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_bf16_kernel(const c
 
         // encoded position as B fragments, evaluated on demand (fc_in and the fc_5 skip connection)
         auto position_frags = [&](bf16x8 (&pe)[2][2]) {  // [blk][s]
-            encode_frags<L_POS, 2>(raw[0], raw[1], raw[2], h, pe);
+            encode_frags<DEFAULT_NET.l_pos, 2>(raw[0], raw[1], raw[2], h, pe);
         };
         // one sub-step = two 32-feature input blocks against all NFB output blocks
         auto sub_step = [&](const char *w, const bf16x8 (&b0)[2], const bf16x8 (&b1)[2], auto nfb_tag) {
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_bf16_kernel(const c
             mma_chunk16<4, 0>(acc, act[5], w + 2 * B16_HALF_CHUNK_BYTES, offs, pipe);
             pipe.issue_done();
             bf16x8 de[1][2];
-            encode_frags<L_DIR, 1>(raw[3], raw[4], raw[5], h, de);
+            encode_frags<DEFAULT_NET.l_dir, 1>(raw[3], raw[4], raw[5], h, de);
             w = ring + pipe.acquire();
             mma_chunk16<4, PIECES>(acc, act[6], w, offs, pipe);
             mma_chunk16<4, 0>(acc, act[7], w + B16_HALF_CHUNK_BYTES, offs, pipe);
@@ -434,8 +435,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_bf16_kernel(const c
 
 }  // namespace
 
-NERF_API int nerf_mlp_forward_bf16(const void *packed_bf16, const float *pos, const float *view_dir, int64_t M,
-                                   float *sigma, float *rgb, nerf_stream_t stream) {
+NERF_API int nerf_mlp_forward_bf16(const nerf_net_t *net_abi, const void *packed_bf16, const float *pos,
+                                   const float *view_dir, int64_t M, float *sigma, float *rgb, nerf_stream_t stream) {
+    mlp::Net net;
+    if (int rc = nerf::fused_net(net_abi, net, "nerf_mlp_forward_bf16")) return rc;
+    if (!net.is_default())   // BASELINE configs[2] is the shipped network; its encodings are compile-time recurrences
+        return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_mlp_forward_bf16: built for the shipped NeRF(63, 27) with "
+                                                "encode levels 10 / 4; other networks run the fp32 kernels");
     NERF_REQUIRE(M >= 0, "nerf_mlp_forward_bf16: negative M");
     if (M == 0) return NERF_OK;
     NERF_REQUIRE(packed_bf16 && pos && view_dir && sigma && rgb, "nerf_mlp_forward_bf16: null pointer");

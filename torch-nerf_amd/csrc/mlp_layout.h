@@ -1,6 +1,9 @@
 // Geometry of the fused NeRF MLP kernels and of the packed weight stream they read.
 //
-// Network (R/network/nerf.py:49-59), fixed: 63 -> 256 x5 -> [63+256] -> 256 x3 -> 257 -> [256+27] -> 128 -> 3.
+// Network (R/network/nerf.py:49-59): E_p -> 256 x5 -> [E_p+256] -> 256 x3 -> 257 -> [256+E_d] -> 128 -> 3 with
+// feat_dim = 256 and any pos_dim E_p <= 64, view_dir_dim E_d <= 32 (struct Net below; the encoded position always
+// occupies two 32-wide k-blocks and the direction one, zero-padded -- 63 / 27 for the reference's shipped yaml).
+// Other feat_dim / wider inputs run the layer-by-layer kernels of mlp_layered.hip.
 //
 // The kernels evaluate Y^T = W . X^T with v_mfma_f32_32x32x2_f32: the WEIGHTS are the
 // A operand (M dimension = output features) and the ACTIVATIONS are the B operand
@@ -23,22 +26,36 @@
 
 namespace mlp {
 
-constexpr int E_POS = 63, E_DIR = 27, FEAT = 256, HALF = 128;
-constexpr int L_POS = 10, L_DIR = 4;
+constexpr int FEAT = 256, HALF = 128;
+constexpr int MAX_E_POS = 64, MAX_E_DIR = 32;   // two / one 32-wide k-blocks
 constexpr int NUM_LAYERS = 11;
 
-// flat parameter blob offsets (state_dict order, weight (out,in) then bias)
-struct LayerDim { int out, in; };
-constexpr LayerDim DIMS[NUM_LAYERS] = {{256, 63},  {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 319},
-                                       {256, 256}, {256, 256}, {257, 256}, {128, 283}, {3, 128}};
-constexpr int64_t w_offset(int l) {
-    int64_t off = 0;
-    for (int i = 0; i < l; ++i) off += (int64_t)DIMS[i].out * DIMS[i].in + DIMS[i].out;
-    return off;
-}
-constexpr int64_t b_offset(int l) { return w_offset(l) + (int64_t)DIMS[l].out * DIMS[l].in; }
-constexpr int64_t PARAM_COUNT = w_offset(NUM_LAYERS);  // 595844
-static_assert(PARAM_COUNT == 595844, "parameter count of NeRF(63, 27, 256)");
+// The network instance a launch works on: NeRF(e_pos, e_dir, 256) and, for the kernels that encode raw points in
+// registers, the two PositionalEncoder(3, levels, include_input) in front of it (positional_encoder.py:27-47;
+// yaml knobs coord_encode_level / dir_encode_level / include_input, runner_utils.py:584-594).  levels < 0: the
+// encoders are not PositionalEncoders -- only pre-encoded inputs are accepted.  Passed to kernels BY VALUE.
+struct Net {
+    int e_pos, e_dir;          // pos_dim, view_dir_dim
+    int l_pos, l_dir;          // encode levels (raw-input kernels)
+    int inc_pos, inc_dir;      // include_input
+    __host__ __device__ constexpr bool is_default() const {
+        return e_pos == 63 && e_dir == 27 && l_pos == 10 && l_dir == 4 && inc_pos == 1 && inc_dir == 1;
+    }
+    __host__ __device__ constexpr int layer_in(int l) const {
+        return l == 0 ? e_pos : l == 5 ? FEAT + e_pos : l == 9 ? FEAT + e_dir : l == 10 ? HALF : FEAT;
+    }
+    static __host__ __device__ constexpr int layer_out(int l) { return l == 8 ? FEAT + 1 : l == 9 ? HALF : l == 10 ? 3 : FEAT; }
+    // flat parameter blob offsets (state_dict order, weight (out,in) then bias)
+    __host__ __device__ constexpr int64_t w_offset(int l) const {
+        int64_t off = 0;
+        for (int i = 0; i < l; ++i) off += (int64_t)layer_out(i) * layer_in(i) + layer_out(i);
+        return off;
+    }
+    __host__ __device__ constexpr int64_t b_offset(int l) const { return w_offset(l) + (int64_t)layer_out(l) * layer_in(l); }
+    __host__ __device__ constexpr int64_t param_count() const { return w_offset(NUM_LAYERS); }
+};
+constexpr Net DEFAULT_NET = {63, 27, 10, 4, 1, 1};
+static_assert(DEFAULT_NET.param_count() == 595844, "parameter count of NeRF(63, 27, 256)");
 
 // ---- const block (resident in LDS for the whole kernel), float offsets
 constexpr int CB_BIAS = 0;            // 8 x 256 : biases of fc_in, fc_1 .. fc_7

@@ -18,27 +18,60 @@ struct Timeline {
 };
 #define NERF_TS() tl.stamp()
 
-// Inputs of this lane's sample: raw[0..2] position, raw[3..5] direction (ENCODED: read from pos/dir rows mc instead).
+// How the tile obtains its two encodings:
+//   IN_ENCODED  pos (M, e_pos), view_dir (M, e_dir) rows already encoded (plain NeRF.forward, any encoder)
+//   IN_SHIPPED  raw points; PositionalEncoder(3, 10, True) / (3, 4, True) -- the reference's shipped yaml -- from the
+//               compile-time table (one sincos per octave and channel, every index a constant)
+//   IN_LEVELS   raw points; PositionalEncoder(3, net.l_pos, net.inc_pos) / (3, net.l_dir, net.inc_dir) with run-time
+//               levels: enc_feature per fragment register (48 sincos + index arithmetic per lane and tile instead of
+//               39), same sincos_cw, so the shipped configuration gives the same bits either way
+enum { IN_ENCODED = 0, IN_SHIPPED = 1, IN_LEVELS = 2 };
+
+// Inputs of this lane's sample: raw[0..2] position, raw[3..5] direction (IN_ENCODED: read from pos/dir rows mc instead).
 // `after_encode()` runs once the raw inputs are consumed (the caller prefetches the next tile's there).
 // Outputs: sigma and the three colours of sample m, valid in the lanes of both halves.
-template <bool ENCODED, bool SAVE, class AfterEncode>
-__device__ __forceinline__ void forward_tile(const float (&raw)[6], const float *__restrict__ pos,
+template <int INPUT, bool SAVE, class AfterEncode>
+__device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[6], const float *__restrict__ pos,
                                              const float *__restrict__ dir, int64_t mc, int64_t m, int64_t MP,
                                              int h, Pipe &pipe, const char *lds, const float *cb, const int (&offq)[4],
                                              float *__restrict__ saved, AfterEncode after_encode, Timeline &tl,
                                              float &sigma_result, float (&y)[3]) {
-    const int in_w = ENCODED ? E_POS : 3, in_wd = ENCODED ? E_DIR : 3;
+    constexpr bool ENCODED = INPUT == IN_ENCODED;
+    const int E_POS = INPUT == IN_SHIPPED ? DEFAULT_NET.e_pos : net.e_pos;
+    const int E_DIR = INPUT == IN_SHIPPED ? DEFAULT_NET.e_dir : net.e_dir;
+    const int L_POS = INPUT == IN_SHIPPED ? DEFAULT_NET.l_pos : net.l_pos;
+    const int L_DIR = INPUT == IN_SHIPPED ? DEFAULT_NET.l_dir : net.l_dir;
     // ---- encodings, straight into B-fragment layout: reg r <-> feature 32 kb + (r&3) + 8 (r>>2) + 4 h
     f32x16 pe[2], de;
     if (ENCODED) {
+        const float *prow = pos + mc * E_POS, *drow = dir + mc * E_DIR;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
-            pe[0][r] = pos[mc * in_w + k];
-            pe[1][r] = (32 + k < E_POS) ? pos[mc * in_w + 32 + k] : 0.0f;
-            de[r] = (k < E_DIR) ? dir[mc * in_wd + k] : 0.0f;
+            pe[0][r] = (k < E_POS) ? prow[k] : 0.0f;
+            pe[1][r] = (32 + k < E_POS) ? prow[32 + k] : 0.0f;
+            de[r] = (k < E_DIR) ? drow[k] : 0.0f;
         }
-    } else if (__builtin_expect(__any(encoding_needs_exact(raw)), 0)) {
+    } else if (INPUT == IN_LEVELS) {
+        // run-time levels; a wave with a huge (or non-finite) coordinate takes the library sin/cos (wave-uniform choice)
+        if (__builtin_expect(__any(encoding_needs_exact(raw, L_POS, L_DIR)), 0)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+                pe[0][r] = enc_feature<true>(k, raw[0], raw[1], raw[2], E_POS, net.inc_pos);
+                pe[1][r] = enc_feature<true>(32 + k, raw[0], raw[1], raw[2], E_POS, net.inc_pos);
+                de[r] = enc_feature<true>(k, raw[3], raw[4], raw[5], E_DIR, net.inc_dir);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+                pe[0][r] = enc_feature<false>(k, raw[0], raw[1], raw[2], E_POS, net.inc_pos);
+                pe[1][r] = enc_feature<false>(32 + k, raw[0], raw[1], raw[2], E_POS, net.inc_pos);
+                de[r] = enc_feature<false>(k, raw[3], raw[4], raw[5], E_DIR, net.inc_dir);
+            }
+        }
+    } else if (__builtin_expect(__any(encoding_needs_exact(raw, L_POS, L_DIR)), 0)) {
         // some lane of this wave has a huge (or non-finite) coordinate: library sin/cos for the tile
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -50,13 +83,13 @@ __device__ __forceinline__ void forward_tile(const float (&raw)[6], const float 
     } else {
         {
             float F[64];
-            encode_table<L_POS, 64>(raw[0], raw[1], raw[2], F);
+            encode_table<DEFAULT_NET.l_pos, 64>(raw[0], raw[1], raw[2], F);
             table_to_fragment(F, 0, h, pe[0]);
             table_to_fragment(F, 1, h, pe[1]);
         }
         {
             float F[32];
-            encode_table<L_DIR, 32>(raw[3], raw[4], raw[5], F);
+            encode_table<DEFAULT_NET.l_dir, 32>(raw[3], raw[4], raw[5], F);
             table_to_fragment(F, 0, h, de);
         }
     }

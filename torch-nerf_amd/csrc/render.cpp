@@ -2,13 +2,14 @@
 // (sample -> fused encode+MLP -> integrate), replacing the reference's Python loop over
 // ray batches (R/renderer/volume_renderer.py:229-254).  Inference only.
 #include "common.h"
+#include "net.h"
 
 namespace {
 inline int64_t align256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 }  // namespace
 
 // render_fused.hip: the whole pass as ONE kernel when the sample count tiles (64, 192, ...)
-int nerf_render_rays_fused(const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc, int Sf,
+int nerf_render_rays_fused(const mlp::Net &net, const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc, int Sf,
                            const float *t_bins, float partition_size, float *weights_in, const float *u1,
                            const float *u2, const float *u3, float *rgb, float *weights_out, int64_t *bin_idx,
                            float *t_out, nerf_stream_t stream);
@@ -21,11 +22,15 @@ NERF_API int64_t nerf_render_workspace_bytes(int64_t n, int S) {
     return 3 * align256(m * 12) + 2 * align256(m * 4);
 }
 
-NERF_API int nerf_render_pass(const void *packed, const float *ray_o, const float *ray_d, int64_t n,
+NERF_API int nerf_render_pass(const nerf_net_t *net_abi, const void *packed, const float *ray_o, const float *ray_d, int64_t n,
                               int Sc, int Sf, const float *t_bins, float partition_size,
                               float *weights_in, const float *u1, const float *u2, const float *u3,
                               float *rgb, float *weights_out, int64_t *bin_idx, float *t, void *workspace,
                               nerf_stream_t stream) {
+    mlp::Net net;
+    if (int rc = nerf::fused_net(net_abi, net, "nerf_render_rays")) return rc;
+    if (!nerf::raw_inputs_ok(net))
+        return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_render_rays: the pass encodes raw sample points: nerf_net_t needs both encode levels");
     NERF_REQUIRE(n >= 0 && Sc > 0 && Sf >= 0, "nerf_render_rays: bad sizes");
     if (n == 0) return NERF_OK;
     NERF_REQUIRE(packed && rgb && weights_out, "nerf_render_rays: null pointer");
@@ -33,7 +38,7 @@ NERF_API int nerf_render_pass(const void *packed, const float *ray_o, const floa
     NERF_REQUIRE(ray_o && ray_d && t_bins && u1 && (!weights_in || Sf == 0 || (u2 && u3)),
                  "nerf_render_rays: null pointer");
     if (nerf_render_is_fused(Sc, Sf, weights_in != nullptr))   // one launch, nothing but rgb + weights written
-        return nerf_render_rays_fused(packed, ray_o, ray_d, n, Sc, Sf, t_bins, partition_size, weights_in, u1, u2,
+        return nerf_render_rays_fused(net, packed, ray_o, ray_d, n, Sc, Sf, t_bins, partition_size, weights_in, u1, u2,
                                       u3, rgb, weights_out, bin_idx, t, stream);
     NERF_REQUIRE(workspace, "nerf_render_rays: this sample count needs the workspace (see nerf_render_workspace_bytes)");
     const int64_t m = n * (int64_t)S;
@@ -51,15 +56,15 @@ NERF_API int nerf_render_pass(const void *packed, const float *ray_o, const floa
         rc = nerf_sample_stratified(ray_o, ray_d, n, Sc, t_bins, partition_size, u1, t, pts, dirs,
                                     delta, stream);
     if (rc != NERF_OK) return rc;
-    rc = nerf_mlp_forward(packed, pts, dirs, m, 0, sigma, radiance, nullptr, stream);
+    rc = nerf_mlp_forward(net_abi, packed, pts, dirs, m, 0, sigma, radiance, nullptr, stream);
     if (rc != NERF_OK) return rc;
     return nerf_composite_forward(sigma, radiance, delta, n, S, rgb, weights_out, stream);
 }
 
-NERF_API int nerf_render_rays(const void *packed, const float *ray_o, const float *ray_d, int64_t n,
+NERF_API int nerf_render_rays(const nerf_net_t *net, const void *packed, const float *ray_o, const float *ray_d, int64_t n,
                               int Sc, int Sf, const float *t_bins, float partition_size,
                               float *weights_in, const float *u1, const float *u2, const float *u3,
                               float *rgb, float *weights_out, void *workspace, nerf_stream_t stream) {
-    return nerf_render_pass(packed, ray_o, ray_d, n, Sc, Sf, t_bins, partition_size, weights_in, u1, u2, u3, rgb,
+    return nerf_render_pass(net, packed, ray_o, ray_d, n, Sc, Sf, t_bins, partition_size, weights_in, u1, u2, u3, rgb,
                             weights_out, nullptr, nullptr, workspace, stream);
 }

@@ -197,7 +197,7 @@ __device__ __forceinline__ void rank_sort_row(int lane, int S, const float *in, 
 // stratified_sampler.py:57-90 + ray_samplers/utils.py:8-58 for one ray: floor the coarse weights in place,
 // inverse-CDF pick of Sf bins, in-bin jitter, sort(cat[coarse, fine]) into the LDS row `t_srt` (Sc + Sf floats).
 // `scratch`: hierarchical_scratch_floats(Sc, Sf) LDS floats private to this wavefront.
-__device__ inline void hierarchical_ray(int lane, int Sc, int Sf, const float *__restrict__ t_bins, float ps,
+__device__ __forceinline__ void hierarchical_ray(int lane, int Sc, int Sf, const float *__restrict__ t_bins, float ps,
                                         float *__restrict__ weights_row, const float *__restrict__ u1_row,
                                         const float *__restrict__ u2_row, const float *__restrict__ u3_row,
                                         int64_t *__restrict__ bin_idx_row, float *scratch, float *t_srt) {

@@ -29,6 +29,7 @@ __device__ int g_nstamps;
 #include "mlp_device.h"
 #include "mlp_tile.h"
 #include "render_device.h"
+#include "net.h"
 
 namespace {
 
@@ -38,6 +39,7 @@ constexpr int BUNCH = 4;            // rays sampled at once: one per wavefront
 constexpr int MAX_GROUP_RAYS = BUNCH;
 
 struct FusedArgs {
+    Net net;
     const char *packed;
     const float *ray_o, *ray_d;
     int64_t n;
@@ -57,6 +59,7 @@ __host__ __device__ inline int fused_lds_floats(int G, int S, int Sc, int Sf) {
     return BUNCH * S + 4 * G * S + 8 * BUNCH + BUNCH * render::hierarchical_scratch_floats(Sc, Sf);
 }
 
+template <int INPUT>
 __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -143,8 +146,8 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
                     }
                 }
                 float sigma, y[3];
-                forward_tile<false, false>(raw, nullptr, nullptr, 0, 0, 0, h, pipe, lds, cb, offq, nullptr, []() {},
-                                           tl, sigma, y);
+                forward_tile<INPUT, false>(a.net, raw, nullptr, nullptr, 0, 0, 0, h, pipe, lds, cb, offq, nullptr,
+                                           []() {}, tl, sigma, y);
                 if (h == 0) {
                     sig_rows[ml] = sigma;
                     rad_rows[3 * ml + 0] = y[0];
@@ -201,12 +204,13 @@ NERF_API int nerf_render_is_fused(int Sc, int Sf, int fine) {
     return group_rays(Sc + (fine ? Sf : 0), Sc, fine ? Sf : 0) > 0;
 }
 
-int nerf_render_rays_fused(const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc, int Sf,
+int nerf_render_rays_fused(const mlp::Net &net, const void *packed, const float *ray_o, const float *ray_d, int64_t n, int Sc, int Sf,
                            const float *t_bins, float partition_size, float *weights_in, const float *u1,
                            const float *u2, const float *u3, float *rgb, float *weights_out, int64_t *bin_idx,
                            float *t_out, nerf_stream_t stream) {
     const int S = Sc + (weights_in ? Sf : 0);
     FusedArgs a;
+    a.net = net;
     a.packed = static_cast<const char *>(packed);
     a.ray_o = ray_o; a.ray_d = ray_d; a.n = n; a.Sc = Sc; a.Sf = weights_in ? Sf : 0;
     a.t_bins = t_bins; a.ps = partition_size; a.weights_in = weights_in;
@@ -214,13 +218,15 @@ int nerf_render_rays_fused(const void *packed, const float *ray_o, const float *
     a.G = group_rays(S, Sc, a.Sf);
     if (a.G == 0) return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_render_rays_fused: sample count does not tile");
     const int lds_bytes = LDS_BYTES + 4 * fused_lds_floats(a.G, S, Sc, a.Sf);
-    static nerf::DeviceMask configured{0};
-    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(render_fused_kernel), 160 * 1024, configured,
+    static nerf::DeviceMask configured[2] = {{0}, {0}};
+    const bool shipped = net.is_default();   // the reference's shipped yaml: compile-time encoding table
+    auto kern = shipped ? render_fused_kernel<IN_SHIPPED> : render_fused_kernel<IN_LEVELS>;
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024, configured[shipped],
                                           "nerf_render_rays: LDS attribute"))
         return rc;
     const int64_t bunches = (n + BUNCH - 1) / BUNCH;
     const int cus = nerf::device_cus();
-    hipLaunchKernelGGL(render_fused_kernel, dim3((unsigned)(bunches < cus ? bunches : cus)), dim3(256), lds_bytes,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(bunches < cus ? bunches : cus)), dim3(256), lds_bytes,
                        nerf::as_stream(stream), a);
     return nerf::check_launch("nerf_render_rays (fused)");
 }

@@ -30,28 +30,46 @@ SIGNATURES = {
     "nerf_sample_hierarchical": (_c_int, [_p, _p, _c_i64, _c_int, _c_int, _p, _c_f, _p, _p, _p, _p, _p,
                                           _p, _p, _p, _p, _p]),
     "nerf_posenc": (_c_int, [_p, _c_i64, _c_int, _c_int, _c_int, _p, _p]),
-    "nerf_mlp_param_count": (_c_i64, []),
-    "nerf_mlp_packed_bytes": (_c_i64, []),
-    "nerf_mlp_pack": (_c_int, [_p, _p, _p]),
+    # every nerf_mlp_* / nerf_render_* entry starts with `const nerf_net_t *net` (NULL = the shipped 63 / 27 / 256)
+    "nerf_mlp_path": (_c_int, [_p]),
+    "nerf_mlp_param_count": (_c_i64, [_p]),
+    "nerf_mlp_packed_bytes": (_c_i64, [_p]),
+    "nerf_mlp_pack": (_c_int, [_p, _p, _p, _p]),
     "nerf_mlp_plane_offset": (_c_i64, [_c_int, _c_i64, _c_int]),
-    "nerf_mlp_saved_bytes": (_c_i64, [_c_i64]),
-    "nerf_mlp_forward": (_c_int, [_p, _p, _p, _c_i64, _c_int, _p, _p, _p, _p]),
-    "nerf_mlp_packed_bf16_bytes": (_c_i64, []),
-    "nerf_mlp_pack_bf16": (_c_int, [_p, _p, _p]),
-    "nerf_mlp_forward_bf16": (_c_int, [_p, _p, _p, _c_i64, _p, _p, _p]),
-    "nerf_mlp_backward_workspace_bytes": (_c_i64, [_c_i64]),
-    "nerf_mlp_backward": (_c_int, [_p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nerf_mlp_saved_bytes": (_c_i64, [_p, _c_i64]),
+    "nerf_mlp_forward": (_c_int, [_p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p, _p]),
+    "nerf_mlp_packed_bf16_bytes": (_c_i64, [_p]),
+    "nerf_mlp_pack_bf16": (_c_int, [_p, _p, _p, _p]),
+    "nerf_mlp_forward_bf16": (_c_int, [_p, _p, _p, _p, _c_i64, _p, _p, _p]),
+    "nerf_mlp_backward_workspace_bytes": (_c_i64, [_p, _c_i64]),
+    "nerf_mlp_backward": (_c_int, [_p, _p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nerf_mlp_layered_record_bytes": (_c_i64, [_p, _c_i64]),
+    "nerf_mlp_layered_workspace_bytes": (_c_i64, [_p, _c_i64]),
+    "nerf_mlp_layered_forward": (_c_int, [_p, _p, _p, _p, _c_i64, _p, _p, _p, _c_i64, _p]),
+    "nerf_mlp_layered_backward": (_c_int, [_p, _p, _p, _p, _c_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nerf_posenc_backward": (_c_int, [_p, _p, _c_i64, _c_int, _c_int, _c_int, _p, _p]),
     "nerf_composite_forward": (_c_int, [_p, _p, _p, _c_i64, _c_int, _p, _p, _p]),
     "nerf_composite_backward": (_c_int, [_p, _p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p]),
     "nerf_render_is_fused": (_c_int, [_c_int, _c_int, _c_int]),
     "nerf_render_workspace_bytes": (_c_i64, [_c_i64, _c_int]),
-    "nerf_render_pass": (_c_int, [_p, _p, _p, _c_i64, _c_int, _c_int, _p, _c_f, _p, _p, _p, _p, _p, _p, _p, _p,
+    "nerf_render_pass": (_c_int, [_p, _p, _p, _p, _c_i64, _c_int, _c_int, _p, _c_f, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _p, _p]),
-    "nerf_render_rays": (_c_int, [_p, _p, _p, _c_i64, _c_int, _c_int, _p, _c_f, _p, _p, _p, _p, _p, _p,
+    "nerf_render_rays": (_c_int, [_p, _p, _p, _p, _c_i64, _c_int, _c_int, _p, _c_f, _p, _p, _p, _p, _p, _p,
                                   _p, _p]),
     "nerf_counter_uniform": (_c_int, [ctypes.c_uint64, _c_i64, _c_i64, _p, _p]),
     "nerf_adam_step": (_c_int, [_p, _p, _p, _p, _c_i64, _c_i64, _c_d, _c_d, _c_d, _c_d, _c_d, _p]),
 }
+
+
+
+class NetStruct(ctypes.Structure):
+    """nerf_net_t (include/nerf_amd.h)."""
+    _fields_ = [("pos_dim", ctypes.c_int32), ("view_dir_dim", ctypes.c_int32), ("feat_dim", ctypes.c_int32),
+                ("pos_levels", ctypes.c_int32), ("pos_include_input", ctypes.c_int32),
+                ("dir_levels", ctypes.c_int32), ("dir_include_input", ctypes.c_int32)]
+
+
+PATH_FUSED, PATH_LAYERED = 0, 1
 
 _lib = None
 
@@ -78,7 +96,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.nerf_amd_abi_version() != 1:
+    if lib.nerf_amd_abi_version() != 2:
         raise RuntimeError("libnerf_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -142,20 +142,100 @@ def posenc(x: torch.Tensor, embed_level: int, include_input: bool) -> torch.Tens
     return out
 
 
+def posenc_backward(x: torch.Tensor, g_out: torch.Tensor, embed_level: int, include_input: bool) -> torch.Tensor:
+    """Gradient autograd returns for `in_signal` of PositionalEncoder.encode (positional_encoder.py:104)."""
+    lib = _lib.load()
+    x, g_out = _gpu(x, "in_signal"), _gpu(g_out, "g_out")
+    M, C = x.shape
+    g_x = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.nerf_posenc_backward(_ptr(x), _ptr(g_out), M, C, embed_level, int(bool(include_input)),
+                                            _ptr(g_x), _stream()), "nerf_posenc_backward")
+    return g_x
+
+
+class PosencFunction(torch.autograd.Function):
+    """PositionalEncoder.encode as a differentiable op (the reference's encode is plain autograd ops)."""
+
+    @staticmethod
+    def forward(ctx, x, embed_level, include_input):
+        ctx.level, ctx.include = int(embed_level), bool(include_input)
+        ctx.save_for_backward(x)
+        return posenc(x, embed_level, include_input)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (x,) = ctx.saved_tensors
+        return posenc_backward(x, g_out.contiguous(), ctx.level, ctx.include), None, None
+
+
 # --------------------------------------------------------------------------- MLP
-def mlp_param_count() -> int:
-    return int(_lib.load().nerf_mlp_param_count())
+class Net:
+    """Which network a call works on -- nerf_net_t of include/nerf_amd.h: NeRF(pos_dim, view_dir_dim, feat_dim)
+    (network/nerf.py:24-63) plus, for the entries that encode raw points in registers, the two
+    PositionalEncoder(3, levels, include_input) in front of it (levels < 0: encoders unknown to the kernels)."""
+
+    def __init__(self, pos_dim=63, view_dir_dim=27, feat_dim=256, pos_levels=10, pos_include_input=True,
+                 dir_levels=4, dir_include_input=True):
+        self.key = (int(pos_dim), int(view_dir_dim), int(feat_dim), int(pos_levels), int(bool(pos_include_input)),
+                    int(dir_levels), int(bool(dir_include_input)))
+        self.struct = _lib.NetStruct(*self.key)
+        self.pos_dim, self.view_dir_dim, self.feat_dim = self.key[:3]
+        self._path = None
+
+    @classmethod
+    def dims_only(cls, pos_dim, view_dir_dim, feat_dim=256):
+        return cls(pos_dim, view_dir_dim, feat_dim, -1, False, -1, False)
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.struct)
+
+    @property
+    def path(self) -> int:
+        """_lib.PATH_FUSED (register-resident kernels) or _lib.PATH_LAYERED (one GEMM launch per layer)."""
+        if self._path is None:
+            self._path = int(_lib.load().nerf_mlp_path(self.ref))
+            if self._path < 0:
+                raise ValueError(f"invalid network description {self.key}: {_lib.load().nerf_amd_last_error().decode()}")
+        return self._path
+
+    @property
+    def fused(self) -> bool:
+        return self.path == _lib.PATH_FUSED
+
+    @property
+    def knows_encoders(self) -> bool:
+        return self.key[3] >= 0 and self.key[5] >= 0
+
+    @property
+    def is_shipped(self) -> bool:
+        return self.key == (63, 27, 256, 10, 1, 4, 1)
+
+    def __repr__(self):
+        return f"Net{self.key}"
 
 
-def mlp_pack(flat_params: torch.Tensor) -> torch.Tensor:
-    """Flat state_dict blob (595844 fp32, GPU) -> packed LDS-image stream (uint8 GPU tensor)."""
+def _ref(net: Optional["Net"]):
+    return None if net is None else net.ref
+
+
+def mlp_param_count(net: Optional[Net] = None) -> int:
+    return int(_lib.load().nerf_mlp_param_count(_ref(net)))
+
+
+def mlp_pack(flat_params: torch.Tensor, net: Optional[Net] = None) -> torch.Tensor:
+    """Flat state_dict blob (fp32, GPU) -> packed LDS-image stream of the fused kernels (uint8 GPU tensor)."""
     lib = _lib.load()
     flat_params = _gpu(flat_params, "flat_params")
-    if flat_params.numel() != lib.nerf_mlp_param_count():
-        raise ValueError(f"expected {lib.nerf_mlp_param_count()} parameters, got {flat_params.numel()}")
-    packed = torch.empty((lib.nerf_mlp_packed_bytes(),), dtype=torch.uint8, device=flat_params.device)
+    if flat_params.numel() != lib.nerf_mlp_param_count(_ref(net)):
+        raise ValueError(f"expected {lib.nerf_mlp_param_count(_ref(net))} parameters, got {flat_params.numel()}")
+    nbytes = lib.nerf_mlp_packed_bytes(_ref(net))
+    if nbytes < 0:
+        raise RuntimeError(f"mlp_pack: {lib.nerf_amd_last_error().decode()}")
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=flat_params.device)
     with torch.cuda.device(flat_params.device):
-        _lib.check(lib.nerf_mlp_pack(_ptr(flat_params), _ptr(packed), _stream()), "nerf_mlp_pack")
+        _lib.check(lib.nerf_mlp_pack(_ref(net), _ptr(flat_params), _ptr(packed), _stream()), "nerf_mlp_pack")
     return packed
 
 
@@ -176,20 +256,29 @@ def _timed(tag, M):
     return e1
 
 
+def _check_rows(pos, view_dir, encoded, net):
+    want_p, want_d = (3, 3) if not encoded else ((63, 27) if net is None else (net.pos_dim, net.view_dir_dim))
+    if pos.ndim != 2 or view_dir.ndim != 2 or pos.shape[0] != view_dir.shape[0] or pos.shape[1] != want_p or \
+            view_dir.shape[1] != want_d:
+        raise ValueError(f"expected pos (M, {want_p}) and view_dir (M, {want_d}); got {tuple(pos.shape)}, "
+                         f"{tuple(view_dir.shape)}")
+
+
 def mlp_forward(packed: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor, encoded: bool,
-                save: bool = False):
+                save: bool = False, net: Optional[Net] = None):
     """Fused encode + NeRF forward.  Returns (sigma (M,), rgb (M,3)[, saved])."""
     lib = _lib.load()
     pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
+    _check_rows(pos, view_dir, encoded, net)
     M = pos.shape[0]
     sigma = torch.empty((M,), dtype=torch.float32, device=pos.device)
     rgb = torch.empty((M, 3), dtype=torch.float32, device=pos.device)
     saved = None
     if save:
-        saved = torch.empty((lib.nerf_mlp_saved_bytes(M) // 4,), dtype=torch.float32, device=pos.device)
+        saved = torch.empty((lib.nerf_mlp_saved_bytes(_ref(net), M) // 4,), dtype=torch.float32, device=pos.device)
     with torch.cuda.device(pos.device):
         end = _timed("mlp_forward", M)
-        _lib.check(lib.nerf_mlp_forward(_ptr(packed), _ptr(pos), _ptr(view_dir), M, int(bool(encoded)),
+        _lib.check(lib.nerf_mlp_forward(_ref(net), _ptr(packed), _ptr(pos), _ptr(view_dir), M, int(bool(encoded)),
                                         _ptr(sigma), _ptr(rgb), _ptr(saved), _stream()),
                    "nerf_mlp_forward")
         if end is not None:
@@ -197,45 +286,47 @@ def mlp_forward(packed: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor,
     return (sigma, rgb, saved) if save else (sigma, rgb)
 
 
-def mlp_pack_bf16(flat_params: torch.Tensor) -> torch.Tensor:
+def mlp_pack_bf16(flat_params: torch.Tensor, net: Optional[Net] = None) -> torch.Tensor:
     """Flat fp32 state_dict blob -> bf16 fragment stream for mlp_forward_bf16 (uint8 GPU tensor)."""
     lib = _lib.load()
     flat_params = _gpu(flat_params, "flat_params")
-    if flat_params.numel() != lib.nerf_mlp_param_count():
-        raise ValueError(f"expected {lib.nerf_mlp_param_count()} parameters, got {flat_params.numel()}")
-    packed = torch.empty((lib.nerf_mlp_packed_bf16_bytes(),), dtype=torch.uint8, device=flat_params.device)
+    if flat_params.numel() != lib.nerf_mlp_param_count(_ref(net)):
+        raise ValueError(f"expected {lib.nerf_mlp_param_count(_ref(net))} parameters, got {flat_params.numel()}")
+    packed = torch.empty((lib.nerf_mlp_packed_bf16_bytes(_ref(net)),), dtype=torch.uint8, device=flat_params.device)
     with torch.cuda.device(flat_params.device):
-        _lib.check(lib.nerf_mlp_pack_bf16(_ptr(flat_params), _ptr(packed), _stream()), "nerf_mlp_pack_bf16")
+        _lib.check(lib.nerf_mlp_pack_bf16(_ref(net), _ptr(flat_params), _ptr(packed), _stream()), "nerf_mlp_pack_bf16")
     return packed
 
 
-def mlp_forward_bf16(packed_bf16: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor):
+def mlp_forward_bf16(packed_bf16: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor, net: Optional[Net] = None):
     """Inference-only bf16-MFMA variant of the fused encode + NeRF forward; pos, view_dir raw (M,3)."""
     lib = _lib.load()
     pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
+    _check_rows(pos, view_dir, False, net)
     M = pos.shape[0]
     sigma = torch.empty((M,), dtype=torch.float32, device=pos.device)
     rgb = torch.empty((M, 3), dtype=torch.float32, device=pos.device)
     with torch.cuda.device(pos.device):
         end = _timed("mlp_forward_bf16", M)
-        _lib.check(lib.nerf_mlp_forward_bf16(_ptr(packed_bf16), _ptr(pos), _ptr(view_dir), M, _ptr(sigma),
+        _lib.check(lib.nerf_mlp_forward_bf16(_ref(net), _ptr(packed_bf16), _ptr(pos), _ptr(view_dir), M, _ptr(sigma),
                                              _ptr(rgb), _stream()), "nerf_mlp_forward_bf16")
         if end is not None:
             end.record()
     return sigma, rgb
 
 
-def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved, g_sigma, g_rgb):
+def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved, g_sigma, g_rgb,
+                 net: Optional[Net] = None):
     """Parameter gradients as one flat tensor in state_dict order."""
     lib = _lib.load()
     M = pos.shape[0]
     g_sigma, g_rgb = _gpu(g_sigma, "g_sigma"), _gpu(g_rgb, "g_rgb")
-    g_params = torch.empty((lib.nerf_mlp_param_count(),), dtype=torch.float32, device=pos.device)
-    ws_bytes = lib.nerf_mlp_backward_workspace_bytes(M)
+    g_params = torch.empty((lib.nerf_mlp_param_count(_ref(net)),), dtype=torch.float32, device=pos.device)
+    ws_bytes = lib.nerf_mlp_backward_workspace_bytes(_ref(net), M)
     ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=pos.device)
     with torch.cuda.device(pos.device):
         end = _timed("mlp_backward", M)
-        _lib.check(lib.nerf_mlp_backward(_ptr(packed), _ptr(flat_params), _ptr(pos), _ptr(view_dir), M,
+        _lib.check(lib.nerf_mlp_backward(_ref(net), _ptr(packed), _ptr(flat_params), _ptr(pos), _ptr(view_dir), M,
                                          int(bool(encoded)), _ptr(sigma), _ptr(rgb), _ptr(saved),
                                          _ptr(g_sigma), _ptr(g_rgb), _ptr(g_params), _ptr(ws), _stream()),
                    "nerf_mlp_backward")
@@ -244,29 +335,42 @@ def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved,
     return g_params
 
 
-class NerfMLPFunction(torch.autograd.Function):
-    """sigma, rgb = NeRF(encode(pos), encode(dir)) with hand-written forward and backward.
+def _split_like(g_flat, shapes):
+    grads, off = [], 0
+    for shp in shapes:
+        n = 1
+        for s in shp:
+            n *= s
+        grads.append(g_flat[off:off + n].view(shp))
+        off += n
+    return grads
 
-    apply(pos, view_dir, encoded, record, packed, flat_params, *params): `params` are the 22
+
+class NerfMLPFunction(torch.autograd.Function):
+    """sigma, rgb = NeRF(encode(pos), encode(dir)) with hand-written forward and backward (fused family).
+
+    apply(pos, view_dir, encoded, record, packed, flat_params, net, *params): `params` are the 22
     nn.Parameters in state_dict order (present so autograd routes their gradients);
-    `flat_params` is their concatenation and `packed` its LDS-image stream.  `record` selects the
-    training-mode kernel that also writes the activation record for backward; the caller decides
-    it from torch.is_grad_enabled() (grad mode is always off inside forward()).
+    `flat_params` is their concatenation and `packed` its LDS-image stream; `net` an ops.Net (None = shipped).
+    `record` selects the training-mode kernel that also writes the activation record for backward; the caller
+    decides it from torch.is_grad_enabled() (grad mode is always off inside forward()).
+    Gradients w.r.t. pos / view_dir are not produced here: NeRF.forward routes such calls to NerfLayeredFunction.
     """
 
     @staticmethod
-    def forward(ctx, pos, view_dir, encoded, record, packed, flat_params, *params):
+    def forward(ctx, pos, view_dir, encoded, record, packed, flat_params, net, *params):
         need_grad = bool(record)
         ctx.encoded = bool(encoded)
+        ctx.net = net
         ctx.shapes = [p.shape for p in params]
         if pos.requires_grad or view_dir.requires_grad:
-            raise RuntimeError("gradients w.r.t. sample positions / directions are not produced by the "
-                               "fused MLP kernel (the reference's runners never request them)")
+            raise RuntimeError("the fused MLP kernels do not return gradients w.r.t. sample positions / directions; "
+                               "NeRF.forward sends such calls through the layered kernels")
         if need_grad:
-            sigma, rgb, saved = mlp_forward(packed, pos, view_dir, encoded, save=True)
+            sigma, rgb, saved = mlp_forward(packed, pos, view_dir, encoded, save=True, net=net)
             ctx.save_for_backward(pos, view_dir, packed, flat_params, sigma, rgb, saved)
         else:
-            sigma, rgb = mlp_forward(packed, pos, view_dir, encoded, save=False)
+            sigma, rgb = mlp_forward(packed, pos, view_dir, encoded, save=False, net=net)
         return sigma, rgb
 
     @staticmethod
@@ -277,15 +381,87 @@ class NerfMLPFunction(torch.autograd.Function):
         if g_rgb is None:
             g_rgb = torch.zeros_like(rgb)
         g_flat = mlp_backward(packed, flat_params, pos, view_dir, ctx.encoded, sigma, rgb, saved,
-                              g_sigma, g_rgb)
-        grads, off = [], 0
-        for shp in ctx.shapes:
-            n = 1
-            for s in shp:
-                n *= s
-            grads.append(g_flat[off:off + n].view(shp))
-            off += n
-        return (None, None, None, None, None, None, *grads)
+                              g_sigma, g_rgb, net=ctx.net)
+        return (None, None, None, None, None, None, None, *_split_like(g_flat, ctx.shapes))
+
+
+# ---- the layered family: any NeRF(pos_dim, view_dir_dim, feat_dim), pre-encoded inputs, input gradients
+LAYERED_INFERENCE_ROWS = 65536     # rows of activation scratch an inference call walks the batch with
+
+
+def mlp_layered_forward(flat_params, pos, view_dir, net: Net, record: bool = False):
+    """NeRF.forward on pre-encoded inputs, one MFMA GEMM launch per layer (csrc/mlp_layered.hip).
+    -> (sigma (M,), rgb (M,3)[, record tensor])."""
+    lib = _lib.load()
+    flat_params, pos, view_dir = _gpu(flat_params, "flat_params"), _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
+    _check_rows(pos, view_dir, True, net)
+    if flat_params.numel() != lib.nerf_mlp_param_count(net.ref):
+        raise ValueError(f"expected {lib.nerf_mlp_param_count(net.ref)} parameters, got {flat_params.numel()}")
+    M = pos.shape[0]
+    rows = M if record else min(M, LAYERED_INFERENCE_ROWS)
+    sigma = torch.empty((M,), dtype=torch.float32, device=pos.device)
+    rgb = torch.empty((M, 3), dtype=torch.float32, device=pos.device)
+    rec = torch.empty((max(lib.nerf_mlp_layered_record_bytes(net.ref, rows), 4) // 4,), dtype=torch.float32,
+                      device=pos.device)
+    with torch.cuda.device(pos.device):
+        end = _timed("mlp_layered_forward", M)
+        _lib.check(lib.nerf_mlp_layered_forward(net.ref, _ptr(flat_params), _ptr(pos), _ptr(view_dir), M, _ptr(sigma),
+                                                _ptr(rgb), _ptr(rec), max(rows, 1), _stream()),
+                   "nerf_mlp_layered_forward")
+        if end is not None:
+            end.record()
+    return (sigma, rgb, rec) if record else (sigma, rgb)
+
+
+def mlp_layered_backward(flat_params, pos, view_dir, net: Net, sigma, rgb, rec, g_sigma, g_rgb,
+                         want_pos: bool = False, want_dir: bool = False):
+    """-> (g_params flat, g_pos (M,pos_dim) | None, g_view_dir (M,view_dir_dim) | None)."""
+    lib = _lib.load()
+    M = pos.shape[0]
+    g_sigma, g_rgb = _gpu(g_sigma, "g_sigma"), _gpu(g_rgb, "g_rgb")
+    dev = pos.device
+    g_params = torch.empty((lib.nerf_mlp_param_count(net.ref),), dtype=torch.float32, device=dev)
+    g_pos = torch.empty_like(pos) if want_pos else None
+    g_dir = torch.empty_like(view_dir) if want_dir else None
+    ws = torch.empty((max(lib.nerf_mlp_layered_workspace_bytes(net.ref, M), 4) // 4,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        end = _timed("mlp_layered_backward", M)
+        _lib.check(lib.nerf_mlp_layered_backward(net.ref, _ptr(flat_params), _ptr(pos), _ptr(view_dir), M, _ptr(sigma),
+                                                 _ptr(rgb), _ptr(rec), _ptr(g_sigma), _ptr(g_rgb), _ptr(g_params),
+                                                 _ptr(g_pos), _ptr(g_dir), _ptr(ws), _stream()),
+                   "nerf_mlp_layered_backward")
+        if end is not None:
+            end.record()
+    return g_params, g_pos, g_dir
+
+
+class NerfLayeredFunction(torch.autograd.Function):
+    """sigma, rgb = NeRF(pos, view_dir) on pre-encoded inputs through the layered kernels; differentiable w.r.t. the
+    22 parameters AND the two inputs (what the reference's autograd provides, nerf.py:102-119).
+    apply(pos, view_dir, record, flat_params, net, *params)."""
+
+    @staticmethod
+    def forward(ctx, pos, view_dir, record, flat_params, net, *params):
+        ctx.net = net
+        ctx.shapes = [p.shape for p in params]
+        pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
+        if record:
+            sigma, rgb, rec = mlp_layered_forward(flat_params, pos, view_dir, net, record=True)
+            ctx.save_for_backward(pos, view_dir, flat_params, sigma, rgb, rec)
+        else:
+            sigma, rgb = mlp_layered_forward(flat_params, pos, view_dir, net, record=False)
+        return sigma, rgb
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb):
+        pos, view_dir, flat_params, sigma, rgb, rec = ctx.saved_tensors
+        if g_sigma is None:
+            g_sigma = torch.zeros_like(sigma)
+        if g_rgb is None:
+            g_rgb = torch.zeros_like(rgb)
+        g_flat, g_pos, g_dir = mlp_layered_backward(flat_params, pos, view_dir, ctx.net, sigma, rgb, rec, g_sigma, g_rgb,
+                                                    want_pos=ctx.needs_input_grad[0], want_dir=ctx.needs_input_grad[1])
+        return (g_pos, g_dir, None, None, None, *_split_like(g_flat, ctx.shapes))
 
 
 # --------------------------------------------------------------------------- draws for sharded jobs (row e)
@@ -372,7 +548,7 @@ def render_is_fused(n_coarse: int, n_fine: int, fine: bool) -> bool:
 
 
 def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, u2=None, u3=None, bf16=False,
-                want_idx=False, want_t=False):
+                want_idx=False, want_t=False, net: Optional[Net] = None):
     """One inference render_scene pass as a single enqueue -> (rgb (n,3), weights (n,S)[, idx (n,Sf)][, t (n,S)]).
     For the sample counts of the reference's configurations (64, 64+128) that is ONE kernel: sampling, the fused
     encode + MLP and the integral, with no intermediate in HBM.  `weights` (fine pass) is floored in place.
@@ -385,7 +561,7 @@ def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, 
         else:
             pts, dirs, delta = sample_hierarchical(ray_o, ray_d, t_bins, partition_size, weights, u1, u2, u3)
         n, S = delta.shape
-        sigma, rgb = mlp_forward_bf16(packed, pts.view(n * S, 3), dirs.view(n * S, 3))
+        sigma, rgb = mlp_forward_bf16(packed, pts.view(n * S, 3), dirs.view(n * S, 3), net=net)
         return composite_forward(sigma.view(n, S), rgb.view(n, S, 3), delta)
     lib = _lib.load()
     ray_o, ray_d, t_bins, u1 = _gpu(ray_o, "ray_o"), _gpu(ray_d, "ray_d"), _gpu(t_bins, "t_bins"), _gpu(u1, "u1")
@@ -410,7 +586,7 @@ def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, 
         if tuple(u2.shape) != (n, Sf) or tuple(u3.shape) != (n, Sf):
             raise ValueError(f"render_rays: u2, u3 must both be ({n}, {Sf}); got {tuple(u2.shape)}, {tuple(u3.shape)}")
     if not (isinstance(packed, torch.Tensor) and packed.is_cuda and packed.is_contiguous()
-            and packed.numel() * packed.element_size() == lib.nerf_mlp_packed_bytes()):
+            and packed.numel() * packed.element_size() == lib.nerf_mlp_packed_bytes(_ref(net))):
         raise ValueError("render_rays: `packed` is not a mlp_pack() stream of this library")
     S = Sc + Sf
     dev = u1.device
@@ -423,7 +599,7 @@ def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, 
         ws = torch.empty((lib.nerf_render_workspace_bytes(n, S),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         end = _timed("render_pass", n * S)
-        _lib.check(lib.nerf_render_pass(_ptr(packed), _ptr(ray_o), _ptr(ray_d), n, Sc, Sf, _ptr(t_bins),
+        _lib.check(lib.nerf_render_pass(_ref(net), _ptr(packed), _ptr(ray_o), _ptr(ray_d), n, Sc, Sf, _ptr(t_bins),
                                         float(partition_size), _ptr(weights), _ptr(u1), _ptr(u2), _ptr(u3),
                                         _ptr(rgb), _ptr(w_out), _ptr(idx), _ptr(t), _ptr(ws), _stream()),
                    "nerf_render_pass")

@@ -129,8 +129,12 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
     t_bins, ps = sampler._create_t_bins(camera.t_near, camera.t_far, n_coarse, device)
     _, flat_c, packed_c = coarse_net._stream()
     _, flat_f, packed_f = fine_net._stream()
+    spec_c, spec_f = coarse_net.inferred_net(), fine_net.inferred_net()   # PositionalEncoders inferred from the widths
+    if spec_c is None or spec_f is None:
+        raise RuntimeError("render_frame runs the fused render pass: feat_dim 256, pos_dim <= 64, view_dir_dim <= 32 "
+                           "behind PositionalEncoders")
     if bf16:  # BASELINE configs[2]: bf16 weights / layer inputs on the bf16 MFMA path
-        packed_c, packed_f = ops.mlp_pack_bf16(flat_c), ops.mlp_pack_bf16(flat_f)
+        packed_c, packed_f = ops.mlp_pack_bf16(flat_c, spec_c), ops.mlp_pack_bf16(flat_f, spec_f)
     out = torch.empty((hi - lo, 3), dtype=torch.float32, device=device)
     # equal launches of at most rays_per_launch rays (a multiple of 4: the fused pass walks bunches of four rays): the
     # persistent kernel then ends every launch with the same, small, last-round imbalance instead of one short tail
@@ -141,9 +145,9 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
         n = min(per_launch, hi - first)
         bundle = sampler.generate_rays_from_pixels(camera, project_to_ndc, first=first, count=n, device=device)
         u1c, u1, u2, u3 = ray_draws(seed, first, n, n_coarse, n_fine, device)
-        rgb, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, bf16=bf16)
+        rgb, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, bf16=bf16, net=spec_c)
         if n_fine > 0:     # n_fine == 0: coarse-only frame (BASELINE configs[0])
             rgb, _ = ops.render_rays(packed_f, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1, weights=w, u2=u2,
-                                     u3=u3, bf16=bf16)
+                                     u3=u3, bf16=bf16, net=spec_f)
         out[first - lo: first - lo + n] = rgb
     return out if single_rank else gather_image(out, total, group)

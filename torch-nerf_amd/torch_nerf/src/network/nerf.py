@@ -6,10 +6,13 @@ ValueErrors, and the same parameter names fc_in, fc_1 .. fc_9, fc_out (.weight (
 .bias) so the reference's checkpoints (runner_utils.py:758-775) load unchanged.
 
 The eleven nn.Linear modules only HOLD the parameters (default init, state_dict layout,
-optimizer visibility); they are never called.  The arithmetic is csrc/mlp_forward.hip /
-mlp_backward.hip behind torch_nerf.amd.ops.NerfMLPFunction.  The kernels are specialised
-for the reference's configured architecture (63 / 27 / 256, configs/network/nerf.yaml +
-signal_encoder/positional_encoding.yaml); other sizes raise -- there is no slow path.
+optimizer visibility); they are never called.  Two kernel families sit underneath (ops.Net.path):
+  * feat_dim == 256, pos_dim <= 64, view_dir_dim <= 32 -- the shipped 63 / 27 / 256 (configs/network/nerf.yaml +
+    signal_encoder/positional_encoding.yaml) and every other coord_encode_level <= 10 / dir_encode_level <= 4 /
+    include_input combination the yaml can express (runner_utils.py:584-612): the register-resident kernels of
+    csrc/mlp_forward.hip / mlp_backward.hip behind torch_nerf.amd.ops.NerfMLPFunction
+  * any other NeRF(pos_dim, view_dir_dim, feat_dim), and any call that wants gradients w.r.t. its inputs: one MFMA
+    GEMM launch per layer, csrc/mlp_layered.hip behind ops.NerfLayeredFunction
 """
 from typing import Tuple
 
@@ -38,6 +41,7 @@ class NeRF(nn.Module):
         self._flat = None
         self._packed = None
         self._packed_bf16 = None
+        self._net = ops.Net.dims_only(pos_dim, view_dir_dim, feat_dim)   # widths only: the encoders live in the scene
         # BASELINE configs[2]: set to True to evaluate no-grad fused queries with bf16 weights and
         # bf16 layer inputs on the bf16 MFMA path (fp32 accumulate).  Training always runs in fp32.
         self.bf16_inference = False
@@ -51,11 +55,8 @@ class NeRF(nn.Module):
         return out
 
     def _stream(self):
-        """(flat blob, packed LDS-image stream), rebuilt only when a parameter changed."""
-        if (self._pos_dim, self._view_dir_dim, self._feat_dim) != (63, 27, 256):
-            raise NotImplementedError(
-                "the HIP kernels are built for NeRF(pos_dim=63, view_dir_dim=27, feat_dim=256); "
-                f"got ({self._pos_dim}, {self._view_dir_dim}, {self._feat_dim})")
+        """(parameters, flat blob, packed LDS-image stream | None for the layered family), rebuilt only when a
+        parameter changed."""
         params = self._ordered_params()
         key = tuple((p.data_ptr(), p._version) for p in params)
         if key != self._pack_key:
@@ -65,7 +66,7 @@ class NeRF(nn.Module):
                 self._flat = self._blob_view(params)
                 if self._flat is None:
                     self._flat = torch.cat([p.detach().reshape(-1) for p in params]).float().contiguous()
-                self._packed = ops.mlp_pack(self._flat)
+                self._packed = ops.mlp_pack(self._flat, self._net) if self._net.fused else None
                 self._packed_bf16 = None
             self._pack_key = key
         return params, self._flat, self._packed
@@ -74,7 +75,7 @@ class NeRF(nn.Module):
         """The bf16 fragment stream of the current parameters (BASELINE configs[2]), packed on first use."""
         _, flat, _ = self._stream()
         if self._packed_bf16 is None:
-            self._packed_bf16 = ops.mlp_pack_bf16(flat)
+            self._packed_bf16 = ops.mlp_pack_bf16(flat, self._net)
         return self._packed_bf16
 
     @staticmethod
@@ -100,7 +101,7 @@ class NeRF(nn.Module):
 
     # ------------------------------------------------------------------ forward paths
     def forward(self, pos: torch.Tensor, view_dir: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """pos (M,63), view_dir (M,27): already encoded.  sigma = relu(.), rgb = sigmoid(.)."""
+        """pos (M,pos_dim), view_dir (M,view_dir_dim): already encoded.  sigma = relu(.), rgb = sigmoid(.)."""
         if (pos.ndim != 2) or (view_dir.ndim != 2):
             raise ValueError(f"Expected 2D tensors. Got {pos.ndim}, {view_dir.ndim}-D tensors.")
         if pos.shape[0] != view_dir.shape[0]:
@@ -110,22 +111,58 @@ class NeRF(nn.Module):
         if view_dir.shape[-1] != self._view_dir_dim:
             raise ValueError(f"Expected {self._view_dir_dim}-D view direction vector. Got {view_dir.shape[-1]}.")
         params, flat, packed = self._stream()
-        return ops.NerfMLPFunction.apply(pos, view_dir, True, self._wants_grad(params), packed, flat, *params)
+        record = self._wants_grad(params)
+        input_grads = torch.is_grad_enabled() and (pos.requires_grad or view_dir.requires_grad)
+        if self._net.fused and not input_grads:
+            return ops.NerfMLPFunction.apply(pos, view_dir, True, record, packed, flat, self._net, *params)
+        # other widths, or gradients w.r.t. the inputs wanted (the reference's autograd provides them)
+        return ops.NerfLayeredFunction.apply(pos, view_dir, record or input_grads, flat, self._net, *params)
+
+    def fused_net(self, coord_enc, dir_enc):
+        """The ops.Net of this network behind the two given encoders if the fused kernels can evaluate the encodings in
+        registers -- both are PositionalEncoder(3, L, include_input) producing exactly pos_dim / view_dir_dim
+        features and the network is in the fused family -- else None."""
+        def level(e, width):
+            if type(e).__name__ != "PositionalEncoder" or getattr(e, "in_dim", None) != 3 or \
+                    getattr(e, "out_dim", None) != width:
+                return None
+            return int(e.embed_level), bool(e.include_input)
+        if not self._net.fused:
+            return None
+        lp, ld = level(coord_enc, self._pos_dim), level(dir_enc, self._view_dir_dim)
+        if lp is None or ld is None:
+            return None
+        key = (lp, ld)
+        if getattr(self, "_fused_net_key", None) != key:
+            self._fused_net_key = key
+            self._fused_net = ops.Net(self._pos_dim, self._view_dir_dim, self._feat_dim, lp[0], lp[1], ld[0], ld[1])
+        return self._fused_net
+
+    def inferred_net(self):
+        """fused_net for PositionalEncoders inferred from the widths alone (6 L + 3 with the input, 6 L without:
+        the two cannot collide), for callers that hold networks but no encoder objects (shard.render_frame)."""
+        def infer(width):
+            return (width // 6, width % 6 == 3) if width % 6 in (0, 3) else None
+        lp, ld = infer(self._pos_dim), infer(self._view_dir_dim)
+        if not self._net.fused or lp is None or ld is None:
+            return None
+        return ops.Net(self._pos_dim, self._view_dir_dim, self._feat_dim, lp[0], lp[1], ld[0], ld[1])
 
     def accepts_fused_encoders(self, coord_enc, dir_enc) -> bool:
-        """True if the two encoders are exactly what the fused kernel computes in registers."""
-        def is_pe(e, level):
-            return (type(e).__name__ == "PositionalEncoder" and getattr(e, "in_dim", None) == 3
-                    and getattr(e, "embed_level", None) == level and getattr(e, "include_input", False))
-        return (self._pos_dim, self._view_dir_dim, self._feat_dim) == (63, 27, 256) and \
-            is_pe(coord_enc, 10) and is_pe(dir_enc, 4)
+        """True if the two encoders are something the fused kernel computes in registers."""
+        return self.fused_net(coord_enc, dir_enc) is not None
 
-    def forward_fused(self, points: torch.Tensor, view_dirs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """points, view_dirs (M,3) RAW: positional encoding happens inside the kernel."""
+    def forward_fused(self, points: torch.Tensor, view_dirs: torch.Tensor, net=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """points, view_dirs (M,3) RAW: positional encoding happens inside the kernel.  `net` = fused_net(encoders);
+        omitted: the shipped encoders (10 / 4 levels, include_input)."""
         params, flat, packed = self._stream()
-        if self.bf16_inference and not self._wants_grad(params):
-            return ops.mlp_forward_bf16(self._stream_bf16(), points, view_dirs)
-        return ops.NerfMLPFunction.apply(points, view_dirs, False, self._wants_grad(params), packed, flat, *params)
+        if net is None:
+            net = self.inferred_net()
+            if net is None:
+                raise RuntimeError(f"NeRF({self._pos_dim}, {self._view_dir_dim}, {self._feat_dim}) has no fused query")
+        if self.bf16_inference and net.is_shipped and not self._wants_grad(params):
+            return ops.mlp_forward_bf16(self._stream_bf16(), points, view_dirs, net)
+        return ops.NerfMLPFunction.apply(points, view_dirs, False, self._wants_grad(params), packed, flat, net, *params)
 
     pos_dim = property(lambda self: self._pos_dim)
     view_dir_dim = property(lambda self: self._view_dir_dim)

@@ -91,7 +91,10 @@ class VolumeRenderer(object):
         from torch_nerf.amd import ops
         if type(self.sampler) is not ray_samplers.StratifiedSampler or \
                 type(self.integrator) is not integrators.QuadratureIntegrator or \
-                type(target_scene) is not scene.PrimitiveCube or not target_scene.fused_query:
+                type(target_scene) is not scene.PrimitiveCube:
+            return None
+        spec = target_scene.fused_net()          # ops.Net: the network behind its two PositionalEncoders
+        if spec is None:
             return None
         net = target_scene.radiance_field
         params, flat, packed = net._stream()
@@ -104,15 +107,15 @@ class VolumeRenderer(object):
         dev = t_bins.device
         origin, direction = ray_bundle.ray_origin.to(dev), ray_bundle.ray_dir.to(dev)
         u1, u2, u3 = self.sampler.draw_uniforms(origin.shape[0], n_coarse, n_fine if hierarchical else 0, dev)
-        bf16 = bool(getattr(net, "bf16_inference", False))
+        bf16 = bool(getattr(net, "bf16_inference", False)) and spec.is_shipped
         if bf16:
             packed = net._stream_bf16()
         if not hierarchical:
-            return ops.render_rays(packed, origin, direction, t_bins, partition_size, u1, bf16=bf16)
+            return ops.render_rays(packed, origin, direction, t_bins, partition_size, u1, bf16=bf16, net=spec)
         w = weights.detach().to(dev)
         w_c = w if (w.is_contiguous() and w.dtype == torch.float32) else w.contiguous().float()
         out = ops.render_rays(packed, origin, direction, t_bins, partition_size, u1, weights=w_c, u2=u2, u3=u3,
-                              bf16=bf16)
+                              bf16=bf16, net=spec)
         if w_c is not w:
             w.copy_(w_c)                                                     # keep the in-place side effect
         return out

@@ -21,21 +21,27 @@ class PrimitiveCube(PrimitiveBase):
             raise ValueError(f"Expected a parameter of type torch.nn.Module. Got {type(radiance_field)}.")
         self._radiance_field = radiance_field
 
+    def fused_net(self):
+        """ops.Net of the network behind its two encoders when query_points can run as the single fused encode+MLP
+        kernel (HIP NeRF of the fused family + two PositionalEncoders of matching widths), else None."""
+        net, enc = self._radiance_field, self._encoders
+        if not hasattr(net, "fused_net") or not enc:
+            return None
+        pe, de = enc.get("coord_enc"), enc.get("dir_enc")
+        return None if pe is None or de is None else net.fused_net(pe, de)
+
     @property
     def fused_query(self) -> bool:
         """True when query_points runs as the single fused encode+MLP kernel."""
-        net, enc = self._radiance_field, self._encoders
-        if not hasattr(net, "forward_fused") or not enc:
-            return False
-        pe, de = enc.get("coord_enc"), enc.get("dir_enc")
-        return bool(pe is not None and de is not None and net.accepts_fused_encoders(pe, de))
+        return self.fused_net() is not None
 
     def query_points(self, pos: torch.Tensor, view_dir: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """pos, view_dir (N,S,3) -> sigma (N,S), radiance (N,S,3)."""
         num_ray, num_sample = super().query_points(pos, view_dir)
         flat = num_ray * num_sample
-        if self.fused_query:
-            sigma, radiance = self._radiance_field.forward_fused(pos.reshape(flat, -1), view_dir.reshape(flat, -1))
+        fused = self.fused_net()
+        if fused is not None and not (torch.is_grad_enabled() and (pos.requires_grad or view_dir.requires_grad)):
+            sigma, radiance = self._radiance_field.forward_fused(pos.reshape(flat, -1), view_dir.reshape(flat, -1), fused)
         else:
             enc = self._encoders or {}
             p, d = pos.reshape(flat, -1), view_dir.reshape(flat, -1)

@@ -20,6 +20,10 @@ class PositionalEncoder(SignalEncoderBase):
         self._out_dim = 2 * embed_level * in_dim + (in_dim if include_input else 0)
 
     def encode(self, in_signal: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and isinstance(in_signal, torch.Tensor) and in_signal.requires_grad:
+            if in_signal.ndim != 2:
+                raise ValueError(f"Expected a 2D tensor (N, C). Got {in_signal.ndim}-D.")
+            return ops.PosencFunction.apply(in_signal, self._embed_level, self._include_input)
         return ops.posenc(in_signal, self._embed_level, self._include_input)
 
     in_dim = property(lambda self: self._in_dim)
