@@ -6,7 +6,10 @@ instruction READS or WRITES a register of v[a:b] before a later `s_waitcnt lgkmc
 the load (N small enough given the hand-issued reads issued after it).
 For every inline-asm `global_store_dwordx4 vaddr, v[a:b], ...` check the hazard hipcc's recognizer cannot see
 inside asm: a store of more than 64 bits needs 2 wait states before a VALU instruction overwrites its data
-registers (gfx940+ "VMEM store more than 64 bits followed by a VALU write of vdata").  Usage:
+registers (gfx940+ "VMEM store more than 64 bits followed by a VALU write of vdata").
+For every inline-asm VMEM instruction (global_* / buffer_*) with an SGPR operand check the other hazard hipcc cannot
+see: a VALU write of an SGPR (v_readfirstlane / v_readlane, which is how a wave-uniform value reaches an "s"
+constraint) needs 5 wait states before a VMEM instruction reads that SGPR.  Usage:
     hipcc ... -save-temps -c kernel.hip ;  python scripts/audit_asm_loads.py kernel-hip-amdgcn-*.s
 """
 import re
@@ -21,11 +24,21 @@ def regs(tok):
     return {int(m.group(1))} if m else set()
 
 
+def sregs(tok):
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"s(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
 def audit(path):
     lines = open(path).read().splitlines()
     in_asm = False
     pending = []  # [regset, line_no, younger_asm_reads]
     stores = []   # [data regset, line_no, wait states seen since the store]
+    sgpr_writes = []   # [sgpr set, line_no, wait states seen since the VALU write]
+    n_vmem_s = 0
     problems = 0
     total = 0
     n_stores = 0
@@ -53,6 +66,27 @@ def audit(path):
             for st in stores:
                 st[2] += int(m_nop.group(1)) + 1 if m_nop else 1
             stores = [st for st in stores if st[2] < 2]
+        # ---- VALU write of an SGPR -> asm VMEM read of it: 5 wait states
+        if in_asm and (op.startswith("global_") or op.startswith("buffer_")):
+            used = set()
+            for t in toks:
+                used |= sregs(t)
+            if used:
+                n_vmem_s += 1
+            for w in sgpr_writes:
+                if used & w[0]:
+                    problems += 1
+                    print(f"{path}:{no}: `{ln[:70]}` reads s{sorted(used & w[0])} {w[2]} wait state(s) after the VALU "
+                          f"write at line {w[1]} (needs 5)")
+        m_nop2 = re.fullmatch(r"s_nop (\d+)", ln)
+        for w in sgpr_writes:
+            w[2] += int(m_nop2.group(1)) + 1 if m_nop2 else 1
+        sgpr_writes = [w for w in sgpr_writes if w[2] < 5]
+        if op in ("v_readfirstlane_b32", "v_readlane_b32") and toks:
+            sgpr_writes.append([sregs(toks[0]), no, 0])
+        elif op.startswith("s_") and toks and not in_asm and op not in ("s_waitcnt", "s_nop", "s_barrier"):
+            for w in sgpr_writes:      # an SALU result replaces the VALU-written value: SALU -> VMEM has no hazard
+                w[0] -= sregs(toks[0])
         if in_asm and op == "global_store_dwordx4" and len(toks) >= 2:
             stores.append([regs(toks[1]), no, 0])
             n_stores += 1
@@ -80,7 +114,7 @@ def audit(path):
             if touched & p[0]:
                 problems += 1
                 print(f"{path}:{no}: `{ln[:70]}` touches v{sorted(touched & p[0])} of the un-waited read at line {p[1]}")
-    print(f"{path}: {n_stores} asm-issued wide stores checked")
+    print(f"{path}: {n_stores} asm-issued wide stores, {n_vmem_s} asm-issued VMEM instructions with SGPR operands checked")
     print(f"{path}: {total} hand-issued LDS reads, {problems} problems")
     return problems
 

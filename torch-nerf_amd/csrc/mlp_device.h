@@ -313,10 +313,22 @@ __device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
-            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3"
-                         :
-                         : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024)
-                         : "memory");
+            // The scalar base comes out of v_readfirstlane (a VALU write of an SGPR), and gfx950 wants 5 wait states
+            // between that and a VMEM instruction reading the SGPR.  hipcc's hazard recognizer cannot see the VMEM
+            // instruction inside the asm, so the FIRST store of the call carries the wait states itself (measured
+            // without them: in the pre-encoded forward, where nothing else sits between the two, one store in ~60
+            // went to the previous plane's address -- stale PE / DE planes, 5 % gradient error, run to run different;
+            // scripts/audit_asm_loads.py now checks every asm VMEM instruction for this).
+            if (fb == 0 && q == 0)
+                asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3"
+                             :
+                             : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024)
+                             : "memory");
+            else
+                asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3"
+                             :
+                             : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024)
+                             : "memory");
         }
     }
 }
