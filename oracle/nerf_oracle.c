@@ -433,13 +433,17 @@ static void linear_bwd(const float *W, int in, int out, const float *x, const fl
 }
 
 /* g_pos (M,E_p) / g_dir (M,E_d): gradients w.r.t. the (encoded) network inputs, what autograd hands back for
- * `pos` / `view_dir` of nerf.py:65-68 (NULL: not wanted).  masks (M, 8 F + F/2) bytes: 1 where the ReLU of
- * h0..h7 (F each) and h9 (F/2) let the unit through (NULL: not wanted) -- tests diff them against the kernel's
- * mask planes to tell ReLU flips at |pre-activation| < 1 ulp from arithmetic error. */
+ * `pos` / `view_dir` of nerf.py:65-68 (NULL: not wanted).  masks (M, 8 F + F/2 + 1) bytes: 1 where the ReLU of
+ * h0..h7 (F each), h9 (F/2) and the density head relu(y8[0]) let the unit through (NULL: not wanted) -- tests diff
+ * them against the kernel's mask planes to tell ReLU flips at |pre-activation| < 1 ulp from arithmetic error.
+ * force_masks (same layout, NULL: the oracle's own): the backward takes its ReLU derivatives from THESE decisions
+ * instead of its own activations -- with the kernel's masks the two backward passes differentiate the same
+ * piecewise-linear function, and what remains is summation-order rounding only. */
 ORC_API void orc_mlp_backward_ex(const float *params, int E_p, int E_d, int F, const float *pos_enc,
                                  const float *dir_enc, int64_t M, const float *g_sigma,
                                  const float *g_rgb, float *g_params /* zero-filled by caller */,
-                                 float *g_pos, float *g_dir, unsigned char *masks)
+                                 float *g_pos, float *g_dir, unsigned char *masks,
+                                 const unsigned char *force_masks)
 {
     layer_t L[NL];
     int64_t total;
@@ -468,36 +472,42 @@ ORC_API void orc_mlp_backward_ex(const float *params, int E_p, int E_d, int F, c
         for (int64_t m = 0; m < M; ++m) {
             mlp_forward_one(params, L, E_p, E_d, F, pos_enc + m * E_p, dir_enc + m * E_d, &A, cat5,
                             cat9, &sg, col);
+            const int64_t mask_row = 8 * (int64_t)F + F / 2 + 1;
             if (masks) {
-                unsigned char *mk = masks + m * (8 * (int64_t)F + F / 2);
+                unsigned char *mk = masks + m * mask_row;
                 for (int l = 0; l < 8; ++l)
                     for (int k = 0; k < F; ++k) mk[l * F + k] = A.h[l][k] > 0.0f;
                 for (int k = 0; k < F / 2; ++k) mk[8 * F + k] = A.h9[k] > 0.0f;
+                mk[8 * F + F / 2] = A.y8[0] > 0.0f;
             }
+            const unsigned char *fm = force_masks ? force_masks + m * mask_row : NULL;
+#define ON_H(l, k) (fm ? fm[(l) * F + (k)] != 0 : A.h[l][k] > 0.0f)
+#define ON_H9(k) (fm ? fm[8 * F + (k)] != 0 : A.h9[k] > 0.0f)
+#define ON_SIGMA (fm ? fm[8 * F + F / 2] != 0 : A.y8[0] > 0.0f)
             /* fc_out: rgb = sigmoid(y10) */
             float gy10[3];
             for (int c = 0; c < 3; ++c) gy10[c] = g_rgb[3 * m + c] * col[c] * (1.0f - col[c]);
             linear_bwd(params + L[10].w_off, F / 2, 3, A.h9, gy10, G + L[10].w_off,
                        G + L[10].b_off, ga, 0, F / 2);
-            for (int k = 0; k < F / 2; ++k) ga[k] = A.h9[k] > 0.0f ? ga[k] : 0.0f;
+            for (int k = 0; k < F / 2; ++k) ga[k] = ON_H9(k) ? ga[k] : 0.0f;
             /* fc_9 on cat9 = [y8[1:], dir] */
             linear_bwd(params + L[9].w_off, F + E_d, F / 2, cat9, ga, G + L[9].w_off,
                        G + L[9].b_off, gcat, 0, g_dir ? F + E_d : F);
             memcpy(gb_ + 1, gcat, sizeof(float) * F);
             if (g_dir) memcpy(g_dir + m * E_d, gcat + F, sizeof(float) * E_d);
             /* y8[0] -> sigma = relu(y8[0]) */
-            gb_[0] = A.y8[0] > 0.0f ? g_sigma[m] : 0.0f;
+            gb_[0] = ON_SIGMA ? g_sigma[m] : 0.0f;
             /* fc_8 (no relu) */
             linear_bwd(params + L[8].w_off, F, F + 1, A.h[7], gb_, G + L[8].w_off, G + L[8].b_off,
                        ga, 0, F);
             for (int l = 7; l >= 6; --l) {
-                for (int k = 0; k < F; ++k) ga[k] = A.h[l][k] > 0.0f ? ga[k] : 0.0f;
+                for (int k = 0; k < F; ++k) ga[k] = ON_H(l, k) ? ga[k] : 0.0f;
                 linear_bwd(params + L[l].w_off, F, F, A.h[l - 1], ga, G + L[l].w_off,
                            G + L[l].b_off, gb_, 0, F);
                 memcpy(ga, gb_, sizeof(float) * F);
             }
             /* fc_5 on cat5 = [pos, h4] */
-            for (int k = 0; k < F; ++k) ga[k] = A.h[5][k] > 0.0f ? ga[k] : 0.0f;
+            for (int k = 0; k < F; ++k) ga[k] = ON_H(5, k) ? ga[k] : 0.0f;
             if (g_pos) {
                 linear_bwd(params + L[5].w_off, F + E_p, F, cat5, ga, G + L[5].w_off, G + L[5].b_off,
                            gcat, 0, F + E_p);
@@ -509,12 +519,12 @@ ORC_API void orc_mlp_backward_ex(const float *params, int E_p, int E_d, int F, c
             }
             memcpy(ga, gb_, sizeof(float) * F);
             for (int l = 4; l >= 1; --l) {
-                for (int k = 0; k < F; ++k) ga[k] = A.h[l][k] > 0.0f ? ga[k] : 0.0f;
+                for (int k = 0; k < F; ++k) ga[k] = ON_H(l, k) ? ga[k] : 0.0f;
                 linear_bwd(params + L[l].w_off, F, F, A.h[l - 1], ga, G + L[l].w_off,
                            G + L[l].b_off, gb_, 0, F);
                 memcpy(ga, gb_, sizeof(float) * F);
             }
-            for (int k = 0; k < F; ++k) ga[k] = A.h[0][k] > 0.0f ? ga[k] : 0.0f;
+            for (int k = 0; k < F; ++k) ga[k] = ON_H(0, k) ? ga[k] : 0.0f;
             linear_bwd(params + L[0].w_off, E_p, F, A.x0, ga, G + L[0].w_off, G + L[0].b_off,
                        g_pos ? gcat : NULL, 0, g_pos ? E_p : 0);
             if (g_pos)   /* autograd adds the two contributions to `pos` (fc_5's skip input, fc_in) */
@@ -536,7 +546,7 @@ ORC_API void orc_mlp_backward(const float *params, int E_p, int E_d, int F, cons
                               const float *dir_enc, int64_t M, const float *g_sigma,
                               const float *g_rgb, float *g_params /* zero-filled by caller */)
 {
-    orc_mlp_backward_ex(params, E_p, E_d, F, pos_enc, dir_enc, M, g_sigma, g_rgb, g_params, NULL, NULL, NULL);
+    orc_mlp_backward_ex(params, E_p, E_d, F, pos_enc, dir_enc, M, g_sigma, g_rgb, g_params, NULL, NULL, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------ */

@@ -166,9 +166,11 @@ def mlp_backward(params, pos_enc, dir_enc, g_sigma, g_rgb, F=256):
     return g
 
 
-def mlp_backward_ex(params, pos_enc, dir_enc, g_sigma, g_rgb, F=256, want_inputs=True, want_masks=False):
+def mlp_backward_ex(params, pos_enc, dir_enc, g_sigma, g_rgb, F=256, want_inputs=True, want_masks=False,
+                    force_masks=None):
     """mlp_backward plus the gradients w.r.t. the encoded inputs (what autograd returns for `pos` / `view_dir` of
-    nerf.py:65-68) and, optionally, the ReLU masks (M, 8 F + F/2) uint8 of h0..h7, h9."""
+    nerf.py:65-68) and, optionally, the ReLU decisions (M, 8 F + F/2 + 1) uint8 of h0..h7, h9 and the density head.
+    force_masks (same layout): differentiate with THESE decisions instead of the oracle's own (see nerf_oracle.c)."""
     params, pos_enc, dir_enc = _f32(params), _f32(pos_enc), _f32(dir_enc)
     g_sigma, g_rgb = _f32(g_sigma), _f32(g_rgb)
     M, E_p = pos_enc.shape
@@ -176,11 +178,15 @@ def mlp_backward_ex(params, pos_enc, dir_enc, g_sigma, g_rgb, F=256, want_inputs
     g = np.zeros_like(params)
     g_pos = np.zeros((M, E_p), np.float32) if want_inputs else None
     g_dir = np.zeros((M, E_d), np.float32) if want_inputs else None
-    masks = np.zeros((M, 8 * F + F // 2), np.uint8) if want_masks else None
+    masks = np.zeros((M, 8 * F + F // 2 + 1), np.uint8) if want_masks else None
+    if force_masks is not None:
+        force_masks = np.ascontiguousarray(force_masks, dtype=np.uint8)
+        assert force_masks.shape == (M, 8 * F + F // 2 + 1)
     lib().orc_mlp_backward_ex(_pf(params), ctypes.c_int(E_p), ctypes.c_int(E_d), ctypes.c_int(F),
                               _pf(pos_enc), _pf(dir_enc), ctypes.c_int64(M), _pf(g_sigma), _pf(g_rgb), _pf(g),
                               None if g_pos is None else _pf(g_pos), None if g_dir is None else _pf(g_dir),
-                              None if masks is None else masks.ctypes.data_as(ctypes.c_void_p))
+                              None if masks is None else masks.ctypes.data_as(ctypes.c_void_p),
+                              None if force_masks is None else force_masks.ctypes.data_as(ctypes.c_void_p))
     return g, g_pos, g_dir, masks
 
 

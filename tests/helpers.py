@@ -31,3 +31,44 @@ def variant_params(g, tag):
     e_p, e_d, feat = (int(v) for v in g[tag + "_dims"][:3])
     return synth.nerf_flat_params(seed=5, pos_dim=e_p, view_dir_dim=e_d, feat_dim=feat, sigma_bias=0.5,
                                   sigma_gain=4.0), (e_p, e_d, feat)
+
+
+def fused_masks(saved, sigma, M):
+    """ReLU decisions of the fused training forward, decoded from the record's mask bit planes (csrc/mlp_layout.h:
+    plane p = h0..h7, h9; per sample m and lane half h one uint4 at index 2m+h whose dword fb>>1, bit 16 (fb&1) + r is
+    (activation > 0) for feature 32 fb + (r&3) + 8 (r>>2) + 4 h), in the oracle's layout (M, 8*256 + 128 + 1)."""
+    MP = (M + 127) // 128 * 128
+    words = saved.cpu().numpy().view(np.uint32)[MP * 2528:].reshape(9, MP, 2, 4)[:, :M]      # [plane][m][h][dword]
+    out = np.zeros((M, 8 * 256 + 128 + 1), np.uint8)
+    for p in range(9):
+        nfb = 4 if p == 8 else 8
+        for fb in range(nfb):
+            for r in range(16):
+                for h in range(2):
+                    k = 32 * fb + (r & 3) + 8 * (r >> 2) + 4 * h
+                    out[:, 256 * p + k] = (words[p, :, h, fb >> 1] >> (16 * (fb & 1) + r)) & 1
+    out[:, -1] = sigma.cpu().numpy() > 0
+    return out
+
+
+def layered_masks(rec, sigma, M, F):
+    """The same decisions from the layered family's record (row-major planes h0..h7 (M,F), y8 (M,F+1), h9 (M,F/2))."""
+    r = rec.cpu().numpy()
+    H = F // 2
+    out = np.zeros((M, 8 * F + H + 1), np.uint8)
+    for l in range(8):
+        out[:, l * F:(l + 1) * F] = r[M * F * l: M * F * (l + 1)].reshape(M, F) > 0
+    h9 = r[M * F * 8 + M * (F + 1): M * F * 8 + M * (F + 1) + M * H].reshape(M, H)
+    out[:, 8 * F:8 * F + H] = h9 > 0
+    out[:, -1] = sigma.cpu().numpy() > 0
+    return out
+
+
+def assert_grads_match_given_masks(got, want, split, tag=""):
+    """With identical ReLU decisions on both sides only summation-order rounding is left: every element of every
+    tensor within 2e-5 relative + 1e-6 of the tensor's rms."""
+    for (k, a), b in zip(split(got).items(), split(want).values()):
+        rms = np.sqrt(np.mean(b.astype(np.float64) ** 2)) + 1e-30
+        bad = np.abs(a - b) > 2e-5 * np.abs(b) + 1e-6 * rms
+        assert not bad.any(), (f"{tag}{k}: {bad.sum()} of {bad.size} elements beyond 2e-5 rel + 1e-6 rms; worst "
+                               f"{np.abs(a - b).max() / rms:.2e} rms")

@@ -48,30 +48,36 @@ def test_mlp_backward_golden(golden, tag):
     check_grad_digest(grad.cpu().numpy(), g, tag + "_grad_", rtol=2e-4, atol_scale=2e-3)
 
 
-@pytest.mark.parametrize("M", [1, 100, 128, 1000, 20000])
+@pytest.mark.parametrize("M", [1, 100, 128, 1000, 5000, 20000])
 def test_mlp_backward_vs_oracle_full_tensor(oracle, M):
-    """Every element of every gradient tensor against the CPU oracle, ragged sizes included."""
+    """Every element of every gradient tensor against the CPU oracle, ragged sizes included.
+    A pre-activation that sits within an ulp of zero can take the other ReLU branch under a different fp32 summation
+    order.  That is measured, not assumed: the kernel's own ReLU decisions are decoded from the record's mask planes,
+    must differ from the oracle's in < 1e-5 of all (sample, unit) pairs, and are then handed to the oracle's backward
+    (force_masks) -- both sides differentiate the same piecewise-linear function, and every element of every tensor
+    must agree within 2e-5 relative + 1e-6 of the tensor's rms (summation-order rounding; the oracle sums in double)."""
+    from helpers import assert_grads_match_given_masks, fused_masks
     rng = np.random.RandomState(M + 3)
     pts = rng.uniform(-4, 4, (M, 3)).astype(np.float32)
     dirs = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
     gs = rng.standard_normal(M).astype(np.float32)
     gc = rng.standard_normal((M, 3)).astype(np.float32)
     flat = synth.nerf_flat_params(seed=11, sigma_bias=0.3, sigma_gain=20.0)
-    ref = oracle.mlp_backward(flat, oracle.posenc(pts, 10), oracle.posenc(dirs, 4), gs, gc)
     fp = dev(flat)
     packed = ops.mlp_pack(fp)
     sigma, rgb, saved = ops.mlp_forward(packed, dev(pts), dev(dirs), encoded=False, save=True)
     got = ops.mlp_backward(packed, fp, dev(pts), dev(dirs), False, sigma, rgb, saved, dev(gs), dev(gc)).cpu().numpy()
-    # A pre-activation that sits within an ulp of zero can take the other ReLU branch under a
-    # different fp32 summation order; that flips one unit's mask for one sample and moves one row
-    # of a gradient by that sample's contribution.  Hence: tight bound on the bulk (99.5 % of the
-    # elements), plus a relative L2 bound on every tensor as a whole.
-    for (k, a), b in zip(synth.split_flat_params(got).items(), synth.split_flat_params(ref).values()):
-        scale = np.sqrt(np.mean(b.astype(np.float64) ** 2)) + 1e-12
-        bad = np.abs(a - b) > (2e-4 * np.abs(b) + 2e-3 * scale)
-        assert bad.mean() <= 0.005, f"{k} (M={M}): {bad.sum()} of {bad.size} elements out of tolerance"
-        rel_l2 = np.linalg.norm((a - b).astype(np.float64)) / (np.linalg.norm(b.astype(np.float64)) + 1e-30)
-        assert rel_l2 <= 1e-3, f"{k} (M={M}): relative L2 error {rel_l2:.2e}"
+    # the oracle on the KERNEL's encodings (the record's PE / DE planes would do too; nerf_posenc's rows differ from the
+    # in-register Cody-Waite values by <= 1.5e-7, which moves gradients by more than the bound below)
+    pe, de = oracle.posenc(pts, 10), oracle.posenc(dirs, 4)
+    _, _, _, own = oracle.mlp_backward_ex(flat, pe, de, gs, gc, want_inputs=False, want_masks=True)
+    masks = fused_masks(saved, sigma, M)
+    flips = masks != own
+    assert flips.mean() < 1e-5, f"{flips.sum()} of {flips.size} ReLU decisions differ from the oracle's"
+    ref = oracle.mlp_backward_ex(flat, pe, de, gs, gc, want_inputs=False, force_masks=masks)[0]
+    # encodings differ by <= 1.5e-7 abs between the kernel (Cody-Waite in registers) and the oracle (libm): that alone
+    # is a 1e-6-relative perturbation of fc_in / fc_5 / fc_9 inputs, inside the bound
+    assert_grads_match_given_masks(got, ref, synth.split_flat_params, f"M={M} ")
 
 
 def test_autograd_function_paths(golden):
