@@ -148,3 +148,62 @@ def test_sharded_frame_equals_single_launch():
                                  u2=u2, u3=u3)
         parts.append(rgb)
     assert torch.equal(torch.cat(parts), a)
+
+
+# ---------------------------------------------------------------- frame-size properties
+def _frame_setup(kind):
+    (net_c, _), (net_f, _) = nets()
+    if kind == "llff":          # configs[3]: 1008 x 756, NDC rays, t in [0, 1]
+        H, W, focal, ndc, near, far = 756, 1008, 815.0, True, 0.0, 1.0
+        pose = synth.llff_like_pose()
+    else:                       # configs[0]: 400 x 400 Blender geometry
+        H = W = 400
+        focal, ndc, near, far = float(synth.blender_focal(W)), False, 2.0, 6.0
+        pose = synth.pose_spherical(37.0, -30.0, 4.0)
+    cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
+                                    torch.from_numpy(pose), near, far)
+    return net_c, net_f, cam, ndc, H, W
+
+
+@pytest.mark.parametrize("kind,n_fine", [("llff", 128), ("coarse400", 0)])
+def test_full_frame_properties(kind, n_fine):
+    """Whole frames of BASELINE configs[3] (LLFF fern geometry, NDC, 64+128) and configs[0] (400x400, coarse-only 64)
+    through shard.render_frame: every pixel finite and inside [0, 1] (weights are a sub-probability, colours a
+    sigmoid), and the image does not depend on how the frame is cut into launches -- bit for bit (the draws are a
+    function of the global ray index, and the kernels have no cross-ray state)."""
+    net_c, net_f, cam, ndc, H, W = _frame_setup(kind)
+    img = shard.render_frame(cam, net_c, net_f, 64, n_fine, ndc, seed=11, single_rank=True)
+    assert img.shape == (H * W, 3) and bool(torch.isfinite(img).all())
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0 + 1e-6
+    assert float(img.std()) > 1e-3                                    # not a constant image
+    for rays_per_launch in (50000, 4096 * 7 + 4):
+        again = shard.render_frame(cam, net_c, net_f, 64, n_fine, ndc, seed=11, single_rank=True,
+                                   rays_per_launch=rays_per_launch)
+        assert torch.equal(img, again), rays_per_launch
+
+
+@pytest.mark.parametrize("kind,fine", [("llff", True), ("coarse400", False)])
+def test_frame_rows_sorted_and_subprobability(kind, fine):
+    """Per-ray properties at frame scale, through the fused pass with its optional outputs: sorted sample positions
+    (t ascending, inside [t_near, t_far + one bin]), weights in [0, 1] with sum <= 1 (transmittance never grows),
+    bin indices inside [0, 63]; pixel colour = sum_i w_i c_i is therefore inside [0, 1].  One image row band of
+    65 536 rays per configuration."""
+    net_c, net_f, cam, ndc, H, W = _frame_setup(kind)
+    n, Sc, Sf = 65536, 64, 128
+    first = (H * W - n) // 2
+    sampler = ray_samplers.StratifiedSampler()
+    bundle = sampler.generate_rays_from_pixels(cam, ndc, first=first, count=n, device=torch.device("cuda"))
+    t_bins, ps = sampler._create_t_bins(cam.t_near, cam.t_far, Sc, torch.device("cuda"))
+    u1c, u1, u2, u3 = shard.ray_draws(5, first, n, Sc, Sf, torch.device("cuda"))
+    _, _, packed_c = net_c._stream()
+    _, _, packed_f = net_f._stream()
+    rgb, w, t = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, want_t=True)
+    if fine:
+        rgb, w, idx, t = ops.render_rays(packed_f, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1, weights=w, u2=u2,
+                                         u3=u3, want_idx=True, want_t=True)
+        assert int(idx.min()) >= 0 and int(idx.max()) <= Sc - 1
+    assert bool((t[:, 1:] >= t[:, :-1]).all()), "sample positions must be sorted along every ray"
+    assert float(t.min()) >= cam.t_near and float(t.max()) <= cam.t_far
+    assert bool(torch.isfinite(w).all()) and float(w.min()) >= 0.0 and float(w.max()) <= 1.0
+    assert float(w.sum(dim=1).max()) <= 1.0 + 1e-5
+    assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0 + 1e-5

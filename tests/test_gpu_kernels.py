@@ -130,6 +130,25 @@ def test_composite(golden, ops, S):
     np.testing.assert_allclose(gs.cpu().numpy(), g[p + "gs_w"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("S", [64, 192, 7])
+def test_composite_backward_vs_fp64_oracle(golden, ops, oracle, S):
+    """The golden d sigma above is what the reference's fp32 autograd produced -- itself only good to ~1e-4 (its
+    cumsum / exp chain cancels in fp32), hence the loose bound there.  The yardstick for the KERNEL is the oracle's
+    reverse pass evaluated in double (nerf_oracle.c:orc_composite_backward): rtol 1e-5, plus 2e-6 of the ray's largest
+    |d sigma| for the elements where T_{i+1} G_i - sum_{k>i} w_k G_k cancels (the kernel's exp() are fp32 like the
+    reference's; its prefix / suffix sums are double)."""
+    g = golden("f6_composite")
+    p = f"S{S}_"
+    sigma, c, delta = g[p + "sigma"], g[p + "c"], g[p + "delta"]
+    for g_w in (None, g[p + "g_w"]):
+        want_s, want_c = oracle.composite_backward(sigma, c, delta, g[p + "g_rgb"], g_w)
+        gs, gc = ops.composite_backward(dev(sigma), dev(c), dev(delta), dev(g[p + "g_rgb"]), None if g_w is None else dev(g_w))
+        scale = np.abs(want_s).max(axis=1, keepdims=True)
+        err = np.abs(gs.cpu().numpy() - want_s)
+        assert np.all(err <= 1e-5 * np.abs(want_s) + 2e-6 * scale), float((err / (1e-5 * np.abs(want_s) + 2e-6 * scale)).max())
+        np.testing.assert_allclose(gc.cpu().numpy(), want_c, rtol=1e-5, atol=1e-7)
+
+
 def test_composite_autograd_function(golden, ops):
     g = golden("f6_composite")
     p = "S64_"
