@@ -145,7 +145,10 @@ def test_composite_backward_vs_fp64_oracle(golden, ops, oracle, S):
         gs, gc = ops.composite_backward(dev(sigma), dev(c), dev(delta), dev(g[p + "g_rgb"]), None if g_w is None else dev(g_w))
         scale = np.abs(want_s).max(axis=1, keepdims=True)
         err = np.abs(gs.cpu().numpy() - want_s)
-        assert np.all(err <= 1e-5 * np.abs(want_s) + 2e-6 * scale), float((err / (1e-5 * np.abs(want_s) + 2e-6 * scale)).max())
+        # (+ 1e-8 absolute: rays whose transmittance has underflowed in fp32 -- sigma = 1e3 in the first bins -- carry
+        # gradients of 1e-13 .. 1e-9 that the double-precision oracle still resolves)
+        bound = 1e-5 * np.abs(want_s) + 2e-6 * scale + 1e-8
+        assert np.all(err <= bound), float((err / bound).max())
         np.testing.assert_allclose(gc.cpu().numpy(), want_c, rtol=1e-5, atol=1e-7)
 
 
