@@ -387,6 +387,13 @@ def runner_loop_leg(device, local_rank, steps, warmup):
     import torch_nerf.src.renderer.cameras as cameras
     renderer, scene_c, scene_f, nets, _, _, focal, _ = build_scene(device)
     from torch_nerf.amd import synth
+    # The runners start with torch.set_num_threads(1) (runner_utils.py:427, _init_torch).  It matters: left at its
+    # default the CPU pool has one thread per visible core (128 on the GPU box, whose cgroup grants 16 CPUs); the
+    # loop's tiny CPU ops (the ground-truth gather) then wake 128 spinning threads, the cgroup runs out of CFS quota
+    # and every thread of the process is frozen until the next 100 ms period -- 30-70 ms stalls with an idle GPU in
+    # every second step (measured: scripts/runner_loop_timeline.py, nr_throttled in /sys/fs/cgroup/cpu.stat).
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(1)
     params = [p for net in nets for p in net.parameters()]
     optimizer = torch.optim.Adam(params, lr=5e-4, eps=1e-8)                      # runner_utils.py:691-695
     scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, pow(0.00005 / 0.0005, 1 / 300000))
@@ -455,7 +462,9 @@ def runner_loop_leg(device, local_rank, steps, warmup):
         step(k, True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    torch.set_num_threads(threads_before)
     return {"ms_per_step": dt / steps * 1e3, "rays_per_s": RAYS * steps / dt, "steps": steps,
+            "torch_num_threads": 1,
             "host_ms_per_step": {k: round(v / steps * 1e3, 3) for k, v in clock.items()},
             "np_random_choice_ms": round(choice_ms, 3),
             "what": "runners/train.py:120-218 verbatim against the drop-in classes: camera per batch, np.random.choice "
@@ -590,6 +599,9 @@ def main():
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # CPU-side torch ops: never more threads than the cgroup grants (the default is one per VISIBLE core; over-
+    # subscribing a CFS quota freezes the whole process for the rest of the 100 ms period)
+    torch.set_num_threads(max(1, host_cores() // max(1, world)))
     ranks_seen = 1
     dist_on = world > 1 or args.force_dist       # every `if dist_on` below is a collective of the N-rank path
     if dist_on:
