@@ -51,6 +51,10 @@ MLP_FLOP_PER_SAMPLE = 2 * 593408
 FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 BF16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA (no 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E spec peak
+# fused render pass, mean of the coarse and the fine launch: per ray o, d (24 B) + rgb (12 B) + draws and weights
+# (coarse: u1 256 B in, weights 256 B out; fine: u1 256 + u2, u3 1024 + weights 256 in and 256 floored back, 768 out)
+# + ONE pass over the 2.57 MB packed weight stream per launch
+ALGORITHMIC_BYTES_PER_LAUNCH = (4096 * (36 + 512) + 4096 * (36 + 256 + 1024 + 512 + 768) + 2 * 2569216) // 2
 
 
 def build_scene(device):
@@ -532,6 +536,72 @@ def configs_leg(nets, flats, device):
     return out
 
 
+def traffic_leg():
+    """HBM traffic of the step's kernels, measured in THIS run: two child processes re-run a
+    short bench (render + bf16 + train legs) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
+    passes, MI355X_MICROARCH.md: the two do not fit one pass), the rocpd databases are read back and summed per
+    dispatch.  Values are RAW counter bytes (KiB x 1024).  The guide's gfx950 note applies: FETCH_SIZE tallies a
+    wide (16 B/lane) streaming read -- the LDS-DMA weight / record streams here -- at HALF its bytes and is
+    uncalibrated for narrow loads, so `fetch_x2` is given beside it as the upper bound."""
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    per = {}          # counter -> kernel name -> [bytes per dispatch]
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="nerf_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out_dir, "-o", "t", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-frame",
+               "--no-stages", "--no-configs", "--no-runner-loop", "--no-traffic"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                timeout=240).returncode
+        except subprocess.TimeoutExpired:
+            return {"error": f"rocprofv3 --pmc {counter} pass timed out"}
+        dbs = [os.path.join(r, f) for r, _, fs in os.walk(out_dir) for f in fs if f.endswith("_results.db")]
+        if rc != 0 or not dbs:
+            return {"error": f"rocprofv3 --pmc {counter} pass failed (rc {rc})"}
+        cur = sqlite3.connect(dbs[0]).cursor()
+        cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+        kname = next(c for c in cols if "kernel_name" in c or c == "name")
+        cname = next(c for c in cols if "counter_name" in c)
+        vname = next(c for c in cols if c in ("value", "counter_value"))
+        did = next(c for c in cols if "dispatch_id" in c)
+        acc = {}
+        for k, c, v, d in cur.execute(f"select {kname}, {cname}, {vname}, {did} from counters_collection"):
+            if c == counter:
+                acc.setdefault(k, {}).setdefault(d, 0.0)
+                acc[k][d] += float(v) * 1024.0            # the counters report KiB
+        per[counter] = {k: list(v.values()) for k, v in acc.items()}
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+    def kernel(needle, pick=None):
+        out = {}
+        for counter, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            vals = [v for k, vs in per[counter].items() if needle in k for v in vs]
+            if pick is not None and vals:
+                vals = pick(vals)
+            out[key] = (sum(vals) / len(vals)) if vals else None
+            out["dispatches"] = len(vals)
+        if out["fetch"] is not None and out["write"] is not None:
+            out["bytes_per_launch"] = out["fetch"] + out["write"]
+            out["fetch_x2"] = 2 * out["fetch"]
+        return out
+
+    big = lambda vals: [v for v in vals if v >= 0.5 * max(vals)]          # the fine-pass launches of a kernel
+    return {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this bench run (2 steps), raw counter bytes",
+            "render_fused_kernel": kernel("render_fused_kernel"),
+            "render_fused_kernel_fine_launch": kernel("render_fused_kernel", big),
+            "mlp_forward_bf16_kernel": kernel("mlp_forward_bf16_kernel"),
+            "render_fused_bf16_kernel": kernel("render_fused_bf16"),
+            "mlp_forward_kernel_record": kernel("mlp_forward_kernel"),
+            "mlp_bwd_dx_kernel": kernel("mlp_bwd_dx_kernel"),
+            "mlp_bwd_dw_kernel": kernel("mlp_bwd_dw_kernel")}
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process (never exec
     from a process that may have initialised the GPU; this one has not) and hand back its return code."""
@@ -558,6 +628,8 @@ def main():
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-MFMA render measurement")
     ap.add_argument("--no-frame", action="store_true", help="skip the 800x800 sharded full-frame leg")
     ap.add_argument("--no-stages", action="store_true", help="skip the HBM-bound stage measurements")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes that measure HBM "
+                    "traffic (roofline.traffic is then null)")
     ap.add_argument("--no-configs", action="store_true", help="skip the llff (configs[3]) and coarse400 (configs[0]) legs")
     ap.add_argument("--no-runner-loop", action="store_true", help="skip the runners/train.py-shaped training loop leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
@@ -676,10 +748,7 @@ def main():
     achieved = total_flop / (total_ms * 1e-3) / 1e12
     fine_ms = float(np.mean([ms for M, ms in durs if M == RAYS * (N_COARSE + N_FINE)]))
     coarse_ms = float(np.mean([ms for M, ms in durs if M == RAYS * N_COARSE]))
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("dominant_kernel_hbm_bytes_per_launch")
+    traffic = None        # filled by traffic_leg() below, from counters collected in this run
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "kernel": ops.DOMINANT_KERNEL + ", 2 launches/step",
@@ -742,6 +811,23 @@ def main():
     if rank == 0 and world == 1 and not args.no_runner_loop and not args.no_train:
         result["runner_loop"] = guarded("runner_loop", lambda: runner_loop_leg(device, local_rank,
                                                                                max(3, args.steps // 4), 2))
+    if rank == 0 and world == 1 and not args.no_traffic:
+        tr = guarded("traffic", traffic_leg)
+        result["traffic"] = tr
+        if "error" not in tr:
+            f32 = tr["render_fused_kernel"]
+            result["roofline"]["traffic"] = f32.get("bytes_per_launch")
+            result["roofline"]["traffic_detail"] = {"fetch": f32.get("fetch"), "write": f32.get("write"),
+                                                    "fetch_x2": f32.get("fetch_x2"),
+                                                    "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_LAUNCH}
+            if isinstance(result.get("bf16"), dict) and "roofline" in result["bf16"]:
+                b16 = tr["render_fused_bf16_kernel"] if tr["render_fused_bf16_kernel"].get("dispatches") else tr["mlp_forward_bf16_kernel"]
+                result["bf16"]["roofline"]["traffic"] = b16.get("bytes_per_launch")
+            if isinstance(result.get("train"), dict) and "roofline" in result["train"]:
+                parts = [tr[k].get("bytes_per_launch") for k in ("mlp_forward_kernel_record", "mlp_bwd_dx_kernel", "mlp_bwd_dw_kernel")]
+                if all(p is not None for p in parts):   # one launch of each per pass; mean over the coarse and fine pass
+                    result["train"]["roofline"]["traffic"] = sum(parts)
+                    result["train"]["roofline"]["traffic_detail"] = dict(zip(("forward_record", "dx_chain", "dw_gemms"), parts))
     if rank == 0 and world == 1 and not args.no_stages:
         result["hbm_stages"] = guarded("hbm_stages", lambda: hbm_stages(device))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
