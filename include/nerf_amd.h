@@ -172,6 +172,16 @@ int nerf_mlp_layered_backward(const nerf_net_t *net, const float *params, const 
 int nerf_posenc_backward(const float *x, const float *g_out, int64_t M, int C, int L, int include_input,
                          float *g_x, nerf_stream_t stream);
 
+/* ---- f4 (second encoder family): SHEncoder.encode, R/signal_encoder/spherical_harmonics_encoder.py:86-139 -- what the
+ * runners put in front of BOTH network inputs under `signal_encoder: sh` (R/../runners/runner_utils.py:595-604).
+ * in_signal (M,3) -> out (M, degree^2), degree 1..5 (the reference defines nothing beyond 25 features), products in
+ * the reference's order (bit-identical fp32 values); nerf_shenc_backward: g_out (M, degree^2) -> g_in (M,3), the
+ * gradient autograd returns for in_signal.  The network behind it is NeRF(degree^2, degree^2): the pre-encoded
+ * entries above with a nerf_net_t whose levels are < 0. */
+int nerf_shenc(const float *in_signal, int64_t M, int degree, float *out, nerf_stream_t stream);
+int nerf_shenc_backward(const float *in_signal, const float *g_out, int64_t M, int degree, float *g_in,
+                        nerf_stream_t stream);
+
 /* ---- a11: QuadratureIntegrator.integrate_along_rays,
  * R/renderer/integrators/quadrature_integrator.py:14-67
  * sigma (n,S), radiance (n,S,3), delta (n,S) -> rgb (n,3), weights (n,S). */

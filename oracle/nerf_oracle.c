@@ -293,6 +293,112 @@ ORC_API void orc_posenc(const float *x, int64_t M, int C, int L, int include_inp
 }
 
 /* ------------------------------------------------------------------ */
+/* f4: SHEncoder.encode.  R/signal_encoder/spherical_harmonics_encoder.py:86-139            */
+/* Real spherical-harmonics basis up to l = 4 on the UN-normalised input (x, y, z); python     */
+/* float coefficients meet fp32 tensors, so every coefficient is rounded to fp32 first and     */
+/* every product / sum is a separately rounded fp32 operation in the reference's order.        */
+/* ------------------------------------------------------------------ */
+static const double SH0 = 0.28209479177387814, SH1 = 0.4886025119029199;
+static const double SH2[5] = {1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792,
+                              0.5462742152960396};
+static const double SH3[7] = {-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
+                              -0.4570457994644658, 1.445305721320277, -0.5900435899266435};
+static const double SH4[9] = {2.5033429417967046, -1.7701307697799304, 0.9461746957575601, -0.6690465435572892,
+                              0.10578554691520431, -0.6690465435572892, 0.47308734787878004, -1.7701307697799304,
+                              0.6258357354491761};
+
+ORC_API void orc_shenc(const float *in, int64_t M, int degree, float *out)
+{
+    const int E = degree * degree;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        const float x = in[3 * m], y = in[3 * m + 1], z = in[3 * m + 2];
+        float *e = out + m * E;
+        e[0] = (float)SH0;
+        if (degree > 1) {
+            e[1] = (float)-SH1 * y; e[2] = (float)SH1 * z; e[3] = (float)-SH1 * x;
+        }
+        if (degree > 2) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            e[4] = (float)SH2[0] * xy;
+            e[5] = (float)SH2[1] * yz;
+            e[6] = (float)SH2[2] * ((2.0f * zz - xx) - yy);
+            e[7] = (float)SH2[3] * xz;
+            e[8] = (float)SH2[4] * (xx - yy);
+            if (degree > 3) {
+                e[9] = ((float)SH3[0] * y) * (3.0f * xx - yy);
+                e[10] = ((float)SH3[1] * xy) * z;
+                e[11] = ((float)SH3[2] * y) * ((4.0f * zz - xx) - yy);
+                e[12] = ((float)SH3[3] * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy);
+                e[13] = ((float)SH3[4] * x) * ((4.0f * zz - xx) - yy);
+                e[14] = ((float)SH3[5] * z) * (xx - yy);
+                e[15] = ((float)SH3[6] * x) * (xx - 3.0f * yy);
+            }
+            if (degree > 4) {
+                e[16] = ((float)SH4[0] * xy) * (xx - yy);
+                e[17] = ((float)SH4[1] * yz) * (3.0f * xx - yy);
+                e[18] = ((float)SH4[2] * xy) * (7.0f * zz - 1.0f);
+                e[19] = ((float)SH4[3] * yz) * (7.0f * zz - 3.0f);
+                e[20] = (float)SH4[4] * (zz * (35.0f * zz - 30.0f) + 3.0f);
+                e[21] = ((float)SH4[5] * xz) * (7.0f * zz - 3.0f);
+                e[22] = ((float)SH4[6] * (xx - yy)) * (7.0f * zz - 1.0f);
+                e[23] = ((float)SH4[7] * xz) * (xx - 3.0f * yy);
+                e[24] = (float)SH4[8] * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+            }
+        }
+    }
+}
+
+/* basis in double (for the reverse pass below) */
+static void sh_basis_d(double x, double y, double z, int degree, double *e)
+{
+    const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    e[0] = SH0;
+    if (degree > 1) { e[1] = -SH1 * y; e[2] = SH1 * z; e[3] = -SH1 * x; }
+    if (degree > 2) {
+        e[4] = SH2[0] * xy; e[5] = SH2[1] * yz; e[6] = SH2[2] * (2.0 * zz - xx - yy); e[7] = SH2[3] * xz;
+        e[8] = SH2[4] * (xx - yy);
+    }
+    if (degree > 3) {
+        e[9] = SH3[0] * y * (3 * xx - yy); e[10] = SH3[1] * xy * z; e[11] = SH3[2] * y * (4 * zz - xx - yy);
+        e[12] = SH3[3] * z * (2 * zz - 3 * xx - 3 * yy); e[13] = SH3[4] * x * (4 * zz - xx - yy);
+        e[14] = SH3[5] * z * (xx - yy); e[15] = SH3[6] * x * (xx - 3 * yy);
+    }
+    if (degree > 4) {
+        e[16] = SH4[0] * xy * (xx - yy); e[17] = SH4[1] * yz * (3 * xx - yy); e[18] = SH4[2] * xy * (7 * zz - 1);
+        e[19] = SH4[3] * yz * (7 * zz - 3); e[20] = SH4[4] * (zz * (35 * zz - 30) + 3);
+        e[21] = SH4[5] * xz * (7 * zz - 3); e[22] = SH4[6] * (xx - yy) * (7 * zz - 1);
+        e[23] = SH4[7] * xz * (xx - 3 * yy); e[24] = SH4[8] * (xx * (xx - 3 * yy) - yy * (3 * xx - yy));
+    }
+}
+
+/* reverse of orc_shenc (autograd in the reference): g_in = J^T g_out with the Jacobian of the polynomials taken by
+ * central differences of the double-precision basis (they are polynomials of degree <= 4: the difference quotient
+ * with h = 1e-3 is exact to ~1e-12 relative; no second hand-derived formula to get wrong) */
+ORC_API void orc_shenc_backward(const float *in, const float *g_out, int64_t M, int degree, float *g_in)
+{
+    const int E = degree * degree;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        const double p[3] = {in[3 * m], in[3 * m + 1], in[3 * m + 2]};
+        for (int c = 0; c < 3; ++c) {
+            /* five-point stencil: exact for polynomials up to degree 4 */
+            const double h = 1e-2 * (fabs(p[c]) > 1.0 ? fabs(p[c]) : 1.0);
+            double q[3], ep2[25], ep1[25], em1[25], em2[25];
+            q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+            q[c] = p[c] + 2 * h; sh_basis_d(q[0], q[1], q[2], degree, ep2);
+            q[c] = p[c] + h;     sh_basis_d(q[0], q[1], q[2], degree, ep1);
+            q[c] = p[c] - h;     sh_basis_d(q[0], q[1], q[2], degree, em1);
+            q[c] = p[c] - 2 * h; sh_basis_d(q[0], q[1], q[2], degree, em2);
+            double acc = 0.0;
+            for (int k = 0; k < E; ++k)
+                acc += (double)g_out[m * E + k] * ((-ep2[k] + 8.0 * ep1[k] - 8.0 * em1[k] + em2[k]) / (12.0 * h));
+            g_in[3 * m + c] = (float)acc;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* a10: the NeRF MLP.  R/network/nerf.py:24-63 (layers), :102-119.     */
 /* Parameters arrive as ONE flat fp32 blob in state_dict order         */
 /* fc_in.weight, fc_in.bias, fc_1.weight, ... fc_out.weight,           */

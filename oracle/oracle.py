@@ -136,6 +136,22 @@ def posenc(x, L, include_input=True):
     return out
 
 
+def shenc(x, degree):
+    """R/signal_encoder/spherical_harmonics_encoder.py:86-139."""
+    x = _f32(x)
+    out = np.empty((x.shape[0], degree * degree), np.float32)
+    lib().orc_shenc(_pf(x), ctypes.c_int64(x.shape[0]), ctypes.c_int(degree), _pf(out))
+    return out
+
+
+def shenc_backward(x, g_out, degree):
+    """Gradient autograd returns for in_signal of SHEncoder.encode."""
+    x, g_out = _f32(x), _f32(g_out)
+    g_in = np.empty_like(x)
+    lib().orc_shenc_backward(_pf(x), _pf(g_out), ctypes.c_int64(x.shape[0]), ctypes.c_int(degree), _pf(g_in))
+    return g_in
+
+
 def nerf_param_count(E_p=63, E_d=27, F=256):
     return int(lib().orc_nerf_param_count(ctypes.c_int(E_p), ctypes.c_int(E_d), ctypes.c_int(F)))
 

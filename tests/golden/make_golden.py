@@ -474,9 +474,54 @@ def f11_net_variants():
     save("f11_net_variants", **out)
 
 
+# ---------------------------------------------------------------- F12 SH encoder
+class _CpuSignal(torch.Tensor):
+    """SHEncoder.encode allocates with device=in_signal.get_device(), which is -1 (an invalid index) for a CPU
+    tensor: the reference's encoder only runs on CUDA tensors.  This subclass answers get_device() with the CPU
+    device so that the reference's OWN statements run unmodified here."""
+    def get_device(self):
+        return torch.device("cpu")
+
+
+def f12_sh_encoder():
+    """signal_encoder: sh (configs/signal_encoder/sh.yaml, runner_utils.py:595-604): SHEncoder(3, degree) on points and
+    directions, NeRF(degree^2, degree^2) behind it; encodings, outputs, parameter-gradient digests and the gradients
+    w.r.t. the raw inputs for degree 4 (the shipped yaml), encodings + input gradients for degrees 1..5."""
+    from torch_nerf.src.signal_encoder.spherical_harmonics_encoder import SHEncoder as RefSH
+    rng = np.random.RandomState(31)
+    M = 96
+    pts = rng.uniform(-2, 2, (M, 3)).astype(np.float32)
+    dirs = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    out = dict(pts=pts, dirs=dirs)
+    for degree in (1, 2, 3, 4, 5):
+        enc = RefSH(3, degree)
+        x = torch.from_numpy(pts.copy()).as_subclass(_CpuSignal).requires_grad_(True)
+        e = enc.encode(x)
+        g_e = torch.from_numpy(rng.standard_normal((M, degree * degree)).astype(np.float32))
+        if e.requires_grad:
+            (e * g_e).sum().backward()
+        out[f"d{degree}_enc"] = e.detach().numpy(); out[f"d{degree}_g_enc"] = g_e.numpy()
+        out[f"d{degree}_g_pts"] = np.zeros_like(pts) if x.grad is None else np.asarray(x.grad)   # degree 1: a constant
+    enc = RefSH(3, 4)
+    x = torch.from_numpy(pts.copy()).as_subclass(_CpuSignal).requires_grad_(True)
+    v = torch.from_numpy(dirs.copy()).as_subclass(_CpuSignal).requires_grad_(True)
+    flat = synth.nerf_flat_params(seed=6, pos_dim=16, view_dir_dim=16, sigma_bias=0.5, sigma_gain=4.0)
+    net = ref_nerf.NeRF(16, 16)
+    net.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in synth.split_flat_params(flat, 16, 16, 256).items()})
+    sigma, rgb = net(enc.encode(x).as_subclass(torch.Tensor), enc.encode(v).as_subclass(torch.Tensor))
+    g_sigma = rng.standard_normal(M).astype(np.float32); g_rgb = rng.standard_normal((M, 3)).astype(np.float32)
+    (sigma * torch.from_numpy(g_sigma)).sum().add((rgb * torch.from_numpy(g_rgb)).sum()).backward()
+    out.update(net_sigma=sigma.detach().numpy(), net_rgb=rgb.detach().numpy(), net_g_sigma=g_sigma, net_g_rgb=g_rgb,
+               net_g_pts=np.asarray(x.grad), net_g_dirs=np.asarray(v.grad))
+    for k, a in grad_digest(net).items():
+        out["net_grad_" + k] = a
+    save("f12_sh_encoder", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    every = dict(f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
+    every = dict(f12=f12_sh_encoder, f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
                  f8=f8_adam)
     for name in (sys.argv[1:] or list(every)):      # e.g. `make_golden.py f8` rewrites one fixture
         every[name]()

@@ -122,6 +122,18 @@ def test_nerf_module_layout_and_errors():
         other(torch.ones(2, 60), torch.ones(2, 24))
 
 
+def test_sh_encoder_contract():
+    """SHEncoder(in_dim, degree): spherical_harmonics_encoder.py:21-84; the runners build it for both inputs and size
+    the network from its out_dim (runner_utils.py:595-612)."""
+    enc = SHEncoder(3, 4)
+    assert (enc.in_dim, enc.degree, enc.out_dim) == (3, 4, 16)
+    net = network.NeRF(enc.out_dim, enc.out_dim)
+    cube = scene.PrimitiveCube(net, {"coord_enc": enc, "dir_enc": enc})
+    assert not cube.fused_query and net._net.fused          # encoders run as kernels, the network in the fused family
+    with pytest.raises(RuntimeError, match="GPU"):
+        enc.encode(torch.ones(4, 3))
+
+
 def test_positional_encoder_dims():
     assert PositionalEncoder(3, 10, True).out_dim == 63
     assert PositionalEncoder(3, 4, True).out_dim == 27

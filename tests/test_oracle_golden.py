@@ -114,6 +114,33 @@ def test_mlp_variants(golden, oracle, tag):
         np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("degree", [1, 2, 3, 4, 5])
+def test_sh_encoder(golden, oracle, degree):
+    """F12: SHEncoder.encode (spherical_harmonics_encoder.py:86-139) -- products in the reference's order, so the
+    fp32 values are BIT-identical; the reverse pass against the reference's autograd."""
+    g = golden("f12_sh_encoder")
+    e = oracle.shenc(g["pts"], degree)
+    assert np.array_equal(e.view(np.uint32), g[f"d{degree}_enc"].view(np.uint32))
+    want = g[f"d{degree}_g_pts"]
+    np.testing.assert_allclose(oracle.shenc_backward(g["pts"], g[f"d{degree}_g_enc"], degree), want, rtol=1e-5,
+                               atol=2e-6 * max(1.0, np.abs(want).max()))
+
+
+def test_sh_network(golden, oracle):
+    """F12: NeRF(16, 16) behind two SHEncoder(3, 4) (signal_encoder: sh, runner_utils.py:595-604)."""
+    g = golden("f12_sh_encoder")
+    flat = synth.nerf_flat_params(seed=6, pos_dim=16, view_dir_dim=16, sigma_bias=0.5, sigma_gain=4.0)
+    pe, de = oracle.shenc(g["pts"], 4), oracle.shenc(g["dirs"], 4)
+    sigma, rgb = oracle.mlp_forward(flat, pe, de)
+    np.testing.assert_allclose(sigma, g["net_sigma"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(rgb, g["net_rgb"], rtol=0, atol=1e-5)
+    grad, g_pe, g_de, _ = oracle.mlp_backward_ex(flat, pe, de, g["net_g_sigma"], g["net_g_rgb"])
+    check_grad_digest(grad, g, "net_grad_", rtol=2e-4, atol_scale=2e-3, dims=(16, 16, 256))
+    for got, want in ((oracle.shenc_backward(g["pts"], g_pe, 4), g["net_g_pts"]),
+                      (oracle.shenc_backward(g["dirs"], g_de, 4), g["net_g_dirs"])):
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5 * np.abs(want).max())
+
+
 @pytest.mark.parametrize("S", [64, 192, 7])
 def test_composite(golden, oracle, S):
     g = golden("f6_composite")

@@ -47,6 +47,8 @@ SIGNATURES = {
     "nerf_mlp_layered_workspace_bytes": (_c_i64, [_p, _c_i64]),
     "nerf_mlp_layered_forward": (_c_int, [_p, _p, _p, _p, _c_i64, _p, _p, _p, _c_i64, _p]),
     "nerf_mlp_layered_backward": (_c_int, [_p, _p, _p, _p, _c_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nerf_shenc": (_c_int, [_p, _c_i64, _c_int, _p, _p]),
+    "nerf_shenc_backward": (_c_int, [_p, _p, _c_i64, _c_int, _p, _p]),
     "nerf_posenc_backward": (_c_int, [_p, _p, _c_i64, _c_int, _c_int, _c_int, _p, _p]),
     "nerf_composite_forward": (_c_int, [_p, _p, _p, _c_i64, _c_int, _p, _p, _p]),
     "nerf_composite_backward": (_c_int, [_p, _p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p]),

@@ -169,6 +169,39 @@ class PosencFunction(torch.autograd.Function):
         return posenc_backward(x, g_out.contiguous(), ctx.level, ctx.include), None, None
 
 
+def shenc(x: torch.Tensor, degree: int) -> torch.Tensor:
+    """SHEncoder.encode (spherical_harmonics_encoder.py:86-139): (M,3) -> (M, degree^2)."""
+    lib = _lib.load()
+    x = _gpu(x, "in_signal")
+    if x.ndim != 2 or x.shape[1] != 3:
+        raise ValueError(f"Expected a (N, 3) tensor. Got {tuple(x.shape)}.")
+    out = torch.empty((x.shape[0], degree * degree), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.nerf_shenc(_ptr(x), x.shape[0], int(degree), _ptr(out), _stream()), "nerf_shenc")
+    return out
+
+
+class ShencFunction(torch.autograd.Function):
+    """SHEncoder.encode as a differentiable op."""
+
+    @staticmethod
+    def forward(ctx, x, degree):
+        ctx.degree = int(degree)
+        ctx.save_for_backward(x)
+        return shenc(x, degree)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (x,) = ctx.saved_tensors
+        lib = _lib.load()
+        g_out = _gpu(g_out, "g_out")
+        g_in = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.nerf_shenc_backward(_ptr(x), _ptr(g_out), x.shape[0], ctx.degree, _ptr(g_in), _stream()),
+                       "nerf_shenc_backward")
+        return g_in, None
+
+
 # --------------------------------------------------------------------------- MLP
 class Net:
     """Which network a call works on -- nerf_net_t of include/nerf_amd.h: NeRF(pos_dim, view_dir_dim, feat_dim)

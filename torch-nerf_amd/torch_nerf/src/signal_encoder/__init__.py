@@ -1,4 +1,4 @@
-"""Signal encoders: `PositionalEncoder` (HIP / fused) and the out-of-scope `SHEncoder` name."""
+"""Signal encoders: `PositionalEncoder` (csrc/posenc.hip, or evaluated in registers by the fused kernels) and `SHEncoder` (csrc/shenc.hip)."""
 from torch_nerf.src.signal_encoder.spherical_harmonics_encoder import SHEncoder
 from torch_nerf.src.signal_encoder.positional_encoder import PositionalEncoder
 
