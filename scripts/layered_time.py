@@ -1,0 +1,31 @@
+"""Throughput of the layered family (csrc/mlp_layered.hip) next to the fused one on the same network."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "torch-nerf_amd")]
+import numpy as np, torch
+from torch_nerf.amd import ops, synth
+torch.cuda.set_device(0)
+def t(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+for (e_p, e_d, F) in ((63, 27, 256), (63, 27, 128), (75, 39, 64), (63, 27, 512)):
+    net = ops.Net.dims_only(e_p, e_d, F)
+    flat = torch.from_numpy(synth.nerf_flat_params(seed=1, pos_dim=e_p, view_dir_dim=e_d, feat_dim=F)).cuda()
+    pe, de = torch.randn(M, e_p, device="cuda"), torch.randn(M, e_d, device="cuda")
+    gs, gc = torch.randn(M, device="cuda"), torch.randn(M, 3, device="cuda")
+    H = F // 2
+    mac = e_p * F + 4 * F * F + (F + e_p) * F + 2 * F * F + F * (F + 1) + (F + e_d) * H + 3 * H
+    fwd = t(lambda: ops.mlp_layered_forward(flat, pe, de, net))
+    sigma, rgb, rec = ops.mlp_layered_forward(flat, pe, de, net, record=True)
+    bwd = t(lambda: ops.mlp_layered_backward(flat, pe, de, net, sigma, rgb, rec, gs, gc))
+    line = f"NeRF({e_p},{e_d},{F}) M={M}: layered fwd {fwd:7.2f} ms = {2*mac*M/fwd/1e9:6.1f} TFLOP/s   bwd {bwd:7.2f} ms = {4*mac*M/bwd/1e9:6.1f} TFLOP/s"
+    if net.fused:
+        packed = ops.mlp_pack(flat, net)
+        f2 = t(lambda: ops.mlp_forward(packed, pe, de, True, net=net))
+        line += f"   | fused fwd {f2:6.2f} ms = {2*mac*M/f2/1e9:6.1f} TFLOP/s"
+    print(line, flush=True)

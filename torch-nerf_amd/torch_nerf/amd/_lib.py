@@ -83,6 +83,11 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def audit() -> None:
+    """Static ISA audit of the kernels that use hand-issued LDS reads / inline-asm VMEM (make -C csrc audit)."""
+    subprocess.check_call(["make", "-C", CSRC, "-j8", "audit"], stdout=subprocess.DEVNULL)
+
+
 def load():
     """Load the shared library (after torch, so both share one HIP runtime)."""
     global _lib
