@@ -698,16 +698,26 @@ def main():
     n_steps = args.warmup + args.steps
     # rank r renders slab (step*world + r) of the frame: contiguous 4096-pixel ranges, resident in HBM
     pix = [((torch.arange(RAYS, device=device) + ((s * world + rank) * RAYS)) % total) for s in range(n_steps)]
-    gathered = torch.empty((world * RAYS, 3), device=device) if dist_on else None
+    # two slabs: the all-gather of step k runs on RCCL's own stream UNDER the render kernels of step k+1 (the design
+    # rule: overlap collectives with compute); a slab is reused only after the gather that filled it has completed
+    gathered = [torch.empty((world * RAYS, 3), device=device) for _ in range(2)] if dist_on else None
+    pending = [None, None]
     torch.manual_seed(1234 + rank)
 
     def step(s):
         _, f_rgb = render_step(renderer, scene_c, scene_f, pix[s], local_rank)
         if dist_on:
-            dist.all_gather_into_tensor(gathered, f_rgb.contiguous())   # assemble the frame slab
+            slot = s & 1
+            if pending[slot] is not None:
+                pending[slot].wait()
+            pending[slot] = dist.all_gather_into_tensor(gathered[slot], f_rgb.contiguous(), async_op=True)   # the frame slab
         return f_rgb
 
     def fence():
+        for slot in (0, 1):                 # every slab of the timed region is assembled before the clock stops
+            if dist_on and pending[slot] is not None:
+                pending[slot].wait()
+                pending[slot] = None
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
