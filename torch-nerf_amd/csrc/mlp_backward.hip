@@ -587,8 +587,16 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
             src = (int64_t)g.a_width * g.x_width + 256 + k;
             dst = (g.flags & FLAG_DENSITY) ? g.w_off + k : table.off_wout + k;
         }
+        // slices are added in index order (bit-reproducible); the loads of four slices are issued together so that the
+        // walk is not one dependent HBM round trip per slice
         float s = 0.0f;
-        for (int sl = 0; sl < g.num_slices; ++sl) s += base[sl * stride + src];
+        int sl = 0;
+        for (; sl + 4 <= g.num_slices; sl += 4) {
+            const float p0 = base[(int64_t)sl * stride + src], p1 = base[(int64_t)(sl + 1) * stride + src];
+            const float p2 = base[(int64_t)(sl + 2) * stride + src], p3 = base[(int64_t)(sl + 3) * stride + src];
+            s += p0; s += p1; s += p2; s += p3;
+        }
+        for (; sl < g.num_slices; ++sl) s += base[(int64_t)sl * stride + src];
         g_params[dst] = s;
     }
 }
@@ -736,7 +744,7 @@ NERF_API int nerf_mlp_backward(const nerf_net_t *net_abi, const void *packed, co
             fclose(f);
         }
     }
-    hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(64, plan.table.n + 1), dim3(256), 0, s, plan.table,
+    hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(256, plan.table.n + 1), dim3(256), 0, s, plan.table,
                        static_cast<const float *>(partial), static_cast<const float *>(bias_partial), (int)dx_grid * 4,
                        g_params);
     return nerf::check_launch("nerf_mlp_backward: reduce");
