@@ -519,9 +519,38 @@ def f12_sh_encoder():
     save("f12_sh_encoder", **out)
 
 
+# ---------------------------------------------------------------- F13 Instant-NGP: does the reference's own module run?
+def f13_instant_ngp():
+    """network: instant_nerf (configs/network/instant_nerf.yaml, runner_utils.py:617-626).  The module constructs, but
+    its forward cannot complete on ANY device: spatial_hash_func builds torch.tensor([[1, 2654435761, 805459861]],
+    dtype=torch.int32) (instant_ngp.py:553-557) and 2654435761 does not fit int32.  Recorded as a fixture so that
+    the claim 'there is no behaviour to be a drop-in for' is a pinned observation, not prose."""
+    import json
+    import torch_nerf.src.network.instant_ngp as ref_ngp
+    rec = {"reference_file": "torch_nerf/src/network/instant_ngp.py", "torch": torch.__version__}
+    net = ref_ngp.InstantNeRF(3, 16, 16, 19, 16, 512, table_feat_dim=2)
+    rec["constructs"] = True
+    rec["num_parameters"] = sum(p.numel() for p in net.parameters())
+    try:
+        net(torch.rand(8, 3).as_subclass(_CpuSignal), torch.rand(8, 16).as_subclass(_CpuSignal))
+        rec["forward_runs"] = True
+    except Exception as exc:  # noqa: BLE001
+        rec["forward_runs"] = False
+        rec["forward_error"] = f"{type(exc).__name__}: {exc}"
+    try:
+        ref_ngp.spatial_hash_func(torch.zeros((4, 3), dtype=torch.int32).as_subclass(_CpuSignal), 1 << 19)
+        rec["spatial_hash_func_runs"] = True
+    except Exception as exc:  # noqa: BLE001
+        rec["spatial_hash_func_runs"] = False
+        rec["spatial_hash_func_error"] = f"{type(exc).__name__}: {exc}"
+    path = os.path.join(HERE, "f13_instant_ngp.json")
+    json.dump(rec, open(path, "w"), indent=1)
+    print(f"wrote {path}: {rec}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    every = dict(f12=f12_sh_encoder, f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
+    every = dict(f13=f13_instant_ngp, f12=f12_sh_encoder, f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
                  f8=f8_adam)
     for name in (sys.argv[1:] or list(every)):      # e.g. `make_golden.py f8` rewrites one fixture
         every[name]()

@@ -122,6 +122,19 @@ def test_nerf_module_layout_and_errors():
         other(torch.ones(2, 60), torch.ones(2, 24))
 
 
+def test_instant_ngp_is_a_name_only_because_the_reference_cannot_run_it():
+    """Fixture F13 (captured by importing the reference): InstantNeRF constructs but its forward dies in
+    spatial_hash_func (int32 overflow of the hash prime) on every device -- there is no behaviour to reproduce, so
+    the drop-in keeps the import name and refuses to construct."""
+    import json
+    import os
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "f13_instant_ngp.json")))
+    assert rec["constructs"] and not rec["forward_runs"] and not rec["spatial_hash_func_runs"]
+    assert "int32" in rec["spatial_hash_func_error"] and "overflow" in rec["spatial_hash_func_error"]
+    with pytest.raises(NotImplementedError):
+        network.InstantNeRF(3, 16, 16, 19, 16, 512)
+
+
 def test_sh_encoder_contract():
     """SHEncoder(in_dim, degree): spherical_harmonics_encoder.py:21-84; the runners build it for both inputs and size
     the network from its out_dim (runner_utils.py:595-612)."""
