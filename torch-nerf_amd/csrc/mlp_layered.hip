@@ -5,8 +5,8 @@
 // encodings (coord_encode_level > 10), any encoder output width -- runs here: one fp32-MFMA GEMM launch per layer with
 // the activations in HBM, the way the reference's eager path does it (nerf.py:102-119), minus its extra passes:
 // bias, ReLU / sigmoid, the two torch.cat (:108, :116) and the ReLU masks of the backward are fused into the GEMMs.
-// Correct first, reasonably fast second: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), 64 x 64 x 16 LDS tiles,
-// register prefetch of the next k-tile; no attempt at the 0.9-of-peak of the fused family.
+// Correct first, reasonably fast second: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), 64..128 x 64..128 x 16 LDS
+// tiles, register prefetch of the next k-tile; no attempt at the 0.9-of-peak of the fused family.
 //
 // One kernel, three roles (all "C[i,j] = sum_k A(i,k) B(k,j)" with run-time strides):
 //   forward   Y[m,n]  = act(sum_k X[m,k] W[n,k] + b[n])     k runs over ONE or TWO concatenated inputs (torch.cat)
@@ -22,7 +22,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TI = 64, TJ = 64, TK = 16, LDT = 65;   // tile; LDS row pitch (floats)
+constexpr int TI = 64, TJ = 64, TK = 16;   // base tile (x WI, x WJ); LDS rows are padded by one float
 
 struct GemmArgs {
     // A operand, element (i, k): segment 1 for k < K1, segment 2 for K1 <= k < K1 + K2 (torch.cat along k)
@@ -52,68 +52,93 @@ __device__ __forceinline__ float load_b(const GemmArgs &g, int64_t k, int j, int
     return j == g.ones_col ? 1.0f : g.B[k * g.b_sk + (int64_t)j * g.b_sj];
 }
 
+// Workgroup tile (64 WI) x (64 WJ): 2 x 2 wavefronts, each (32 WI) x (32 WJ) = WI * WJ accumulator blocks.  The wider
+// tiles halve the LDS reads and the staging work per MFMA (a 64 x 64 tile reads two fragments per MFMA, a 128 x 128
+// tile one); the launcher picks the widest tile the output extent fills.
+template <int WI, int WJ>
 __global__ __launch_bounds__(256) void layered_gemm_kernel(const GemmArgs g) {
-    __shared__ float As[TK][LDT], Bs[TK][LDT];
+    constexpr int TI_ = TI * WI, TJ_ = TJ * WJ;
+    __shared__ float As[TK][TI_ + 1], Bs[TK][TJ_ + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    const int64_t i0 = (int64_t)blockIdx.x * TI;
-    const int j0 = blockIdx.y * TJ;
+    const int64_t i0 = (int64_t)blockIdx.x * TI_;
+    const int j0 = blockIdx.y * TJ_;
     const int64_t K = g.K1 + g.K2;
     const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
     const int64_t k_end = k_begin + g.k_chunk < K ? k_begin + g.k_chunk : K;
 
-    // thread -> (row, k) of the four tile elements it stages per operand
-    int ar[4], ak[4], br[4], bk[4];
+    // thread -> (row, k) of the 4 WI (4 WJ) tile elements it stages of the A (B) operand
+    constexpr int NA = 4 * WI, NB = 4 * WJ;
+    int ar[NA], ak[NA], br[NB], bk[NB];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NA; ++it) {
         if (g.a_kfast) { ak[it] = tid & 15; ar[it] = (tid >> 4) + 16 * it; }
-        else           { ar[it] = tid & 63; ak[it] = (tid >> 6) + 4 * it; }
-        if (g.b_kfast) { bk[it] = tid & 15; br[it] = (tid >> 4) + 16 * it; }
-        else           { br[it] = tid & 63; bk[it] = (tid >> 6) + 4 * it; }
+        else           { ar[it] = tid % TI_; ak[it] = tid / TI_ + (256 / TI_) * it; }
     }
-    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int it = 0; it < NB; ++it) {
+        if (g.b_kfast) { bk[it] = tid & 15; br[it] = (tid >> 4) + 16 * it; }
+        else           { br[it] = tid % TJ_; bk[it] = tid / TJ_ + (256 / TJ_) * it; }
+    }
+    f32x16 acc[WI][WJ];
+#pragma unroll
+    for (int a = 0; a < WI; ++a)
+#pragma unroll
+        for (int b = 0; b < WJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    float ra[4], rb[4];
+    float ra[NA], rb[NB];
     auto fetch = [&](int64_t kt) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            ra[it] = load_a(g, i0 + ar[it], kt + ak[it], k_end);
-            rb[it] = load_b(g, kt + bk[it], j0 + br[it], k_end);
-        }
+        for (int it = 0; it < NA; ++it) ra[it] = load_a(g, i0 + ar[it], kt + ak[it], k_end);
+#pragma unroll
+        for (int it = 0; it < NB; ++it) rb[it] = load_b(g, kt + bk[it], j0 + br[it], k_end);
     };
     if (k_begin < k_end) fetch(k_begin);
     for (int64_t kt = k_begin; kt < k_end; kt += TK) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            As[ak[it]][ar[it]] = ra[it];
-            Bs[bk[it]][br[it]] = rb[it];
-        }
+        for (int it = 0; it < NA; ++it) As[ak[it]][ar[it]] = ra[it];
+#pragma unroll
+        for (int it = 0; it < NB; ++it) Bs[bk[it]][br[it]] = rb[it];
         __syncthreads();
         if (kt + TK < k_end) fetch(kt + TK);   // the next tile's loads fly under this tile's MFMAs
 #pragma unroll
-        for (int kk = 0; kk < TK / 2; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + (lane >> 5)][wi * 32 + (lane & 31)],
-                                                      Bs[2 * kk + (lane >> 5)][wj * 32 + (lane & 31)], acc, 0, 0, 0);
+        for (int kk = 0; kk < TK / 2; ++kk) {
+            float fa[WI], fb[WJ];
+#pragma unroll
+            for (int a = 0; a < WI; ++a) fa[a] = As[2 * kk + (lane >> 5)][(wi * WI + a) * 32 + (lane & 31)];
+#pragma unroll
+            for (int b = 0; b < WJ; ++b) fb[b] = Bs[2 * kk + (lane >> 5)][(wj * WJ + b) * 32 + (lane & 31)];
+#pragma unroll
+            for (int a = 0; a < WI; ++a)
+#pragma unroll
+                for (int b = 0; b < WJ; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
         __syncthreads();
     }
 
-    // D fragment: register r of lane l is row (r&3) + 8 (r>>2) + 4 (l>>5), column l&31 of the wave's 32 x 32 block
-    const int j = j0 + wj * 32 + (lane & 31);
-    if (j >= g.J) return;
+    // D fragment: register r of lane l is row (r&3) + 8 (r>>2) + 4 (l>>5), column l&31 of a 32 x 32 block
     float *C = g.C + (int64_t)blockIdx.z * g.c_slice;
-    const float bj = g.bias ? g.bias[j] : 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (i >= g.I) continue;
-        float v = acc[r] + bj;
-        if (g.act == 1) v = v > 0.0f ? v : 0.0f;
-        else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
-        if (g.mask) v = g.mask[i * g.mask_si + j] > 0.0f ? v : 0.0f;
-        float *dst = C + i * g.c_si + j;
-        *dst = g.accumulate ? *dst + v : v;
+    for (int b = 0; b < WJ; ++b) {
+        const int j = j0 + (wj * WJ + b) * 32 + (lane & 31);
+        if (j >= g.J) continue;
+        const float bj = g.bias ? g.bias[j] : 0.0f;
+#pragma unroll
+        for (int a = 0; a < WI; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t i = i0 + (wi * WI + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (i >= g.I) continue;
+                float v = acc[a][b][r] + bj;
+                if (g.act == 1) v = v > 0.0f ? v : 0.0f;
+                else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
+                if (g.mask) v = g.mask[i * g.mask_si + j] > 0.0f ? v : 0.0f;
+                float *dst = C + i * g.c_si + j;
+                *dst = g.accumulate ? *dst + v : v;
+            }
     }
 }
 
@@ -186,10 +211,18 @@ GemmArgs blank() {
     return g;
 }
 
+// tile shape by output extent: 128 wide where the extent fills it (narrow layers keep 64 and waste no lanes)
+inline int tile_i(int I) { return I >= 128 ? 128 : 64; }
+inline int tile_j(int J) { return J >= 128 ? 128 : 64; }
+
 int launch(const GemmArgs &g, int slices, hipStream_t s, const char *what) {
     if (g.I <= 0 || g.J <= 0) return NERF_OK;
-    hipLaunchKernelGGL(layered_gemm_kernel, dim3((unsigned)((g.I + TI - 1) / TI), (unsigned)((g.J + TJ - 1) / TJ),
-                                                 (unsigned)slices), dim3(256), 0, s, g);
+    const int ti = tile_i(g.I), tj = tile_j(g.J);
+    const dim3 grid((unsigned)((g.I + ti - 1) / ti), (unsigned)((g.J + tj - 1) / tj), (unsigned)slices);
+    if (ti == 128 && tj == 128) hipLaunchKernelGGL((layered_gemm_kernel<2, 2>), grid, dim3(256), 0, s, g);
+    else if (ti == 128) hipLaunchKernelGGL((layered_gemm_kernel<2, 1>), grid, dim3(256), 0, s, g);
+    else if (tj == 128) hipLaunchKernelGGL((layered_gemm_kernel<1, 2>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((layered_gemm_kernel<1, 1>), grid, dim3(256), 0, s, g);
     return nerf::check_launch(what);
 }
 
@@ -222,7 +255,7 @@ int linear_dx(const float *P, const Layout &L, int layer, const float *G, int64_
 
 // fixed slicing of the sample axis (a function of M and the tile grid only: never of the device)
 int dw_slices(int64_t M, int I, int J) {
-    const int64_t tiles = (int64_t)((I + TI - 1) / TI) * ((J + TJ - 1) / TJ);
+    const int64_t tiles = (int64_t)((I + tile_i(I) - 1) / tile_i(I)) * ((J + tile_j(J) - 1) / tile_j(J));
     int64_t want = (1024 + tiles - 1) / tiles;
     const int64_t most = (M + 511) / 512;          // at least 512 rows per slice
     if (want > most) want = most;
@@ -256,13 +289,13 @@ int64_t align64(int64_t floats) { return (floats + 63) & ~(int64_t)63; }
 int64_t partial_floats(const Layout &L) {   // the largest slices * I * J over the dW calls of the backward, for any M
     int64_t most = 0;
     auto piece = [&](int I, int J) {
-        const int64_t tiles = (int64_t)((I + TI - 1) / TI) * ((J + TJ - 1) / TJ);
+        const int64_t tiles = (int64_t)((I + tile_i(I) - 1) / tile_i(I)) * ((J + tile_j(J) - 1) / tile_j(J));
         int64_t s = (1024 + tiles - 1) / tiles;
         if (s > 256) s = 256;
         if (s * I * J > most) most = s * (int64_t)I * J;
     };
     for (int l = 0; l < 11; ++l) {
-        if (l == 5) { piece(L.out[l], L.E_p); piece(L.out[l], L.F + 1); }
+        if (l == 5) { piece(L.out[l], L.E_p); piece(L.out[l], L.F + 1); }          // (the bias column counts)
         else if (l == 9) { piece(L.out[l], L.F + 1); piece(L.out[l], L.E_d); }
         else piece(L.out[l], L.in[l] + 1);
     }
