@@ -211,9 +211,17 @@ GemmArgs blank() {
     return g;
 }
 
-// tile shape by output extent: 128 wide where the extent fills it (narrow layers keep 64 and waste no lanes)
+// Tile shape.  The kernel is templated on 64- or 128-wide tiles per direction; the 128-wide ones (two accumulator
+// blocks per wavefront and direction, half the LDS reads per MFMA) were measured and are SLOWER -- 60 / 43 instead of
+// 61.5 / 53 TFLOP/s forward / backward at feat_dim 256 -- because the kernel is bound by its bounds-checked scalar
+// staging loads, which the 64 x 64 tile hides behind four workgroups per CU.  So: 64 x 64 everywhere.
+#ifdef X_LAYERED_WIDE
 inline int tile_i(int I) { return I >= 128 ? 128 : 64; }
 inline int tile_j(int J) { return J >= 128 ? 128 : 64; }
+#else
+inline int tile_i(int) { return 64; }
+inline int tile_j(int) { return 64; }
+#endif
 
 int launch(const GemmArgs &g, int slices, hipStream_t s, const char *what) {
     if (g.I <= 0 || g.J <= 0) return NERF_OK;
