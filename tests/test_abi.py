@@ -90,3 +90,38 @@ def test_render_is_fused_is_a_host_side_rule():
                                (32, 0, 0, 1), (32, 64, 1, 1), (64, 192, 1, 1),
                                (40, 0, 0, 0), (40, 24, 1, 1), (1000, 16, 1, 0), (100, 0, 0, 0), (0, 0, 0, 0), (64, -1, 1, 0)]:
         assert lib.nerf_render_is_fused(sc, sf, fine) == want, (sc, sf, fine)
+
+
+def test_entry_points_refuse_what_they_cannot_serve_before_touching_the_gpu():
+    """Argument validation is host code and runs without a GPU: a network outside the fused family is refused by the
+    fused entries with NERF_ERR_UNSUPPORTED (and pointed at nerf_mlp_layered_*), raw-input entries need encode
+    levels, the bf16 variant is bound to the shipped network, SH degrees beyond 5 do not exist, M = 0 is a no-op."""
+    import ctypes
+    lib = _lib.load()
+    OK, ARG, UNSUPPORTED = 0, 1, 2
+    net = lambda *v: ctypes.byref(_lib.NetStruct(*v))
+    f128 = net(63, 27, 128, 10, 1, 4, 1)
+    assert lib.nerf_mlp_pack(f128, None, None, None) == ARG                       # null pointers first
+    one = ctypes.c_float(0.0)
+    p = ctypes.cast(ctypes.pointer(one), ctypes.c_void_p)                          # any non-null address: never dereferenced
+    assert lib.nerf_mlp_pack(f128, p, p, None) == UNSUPPORTED and b"nerf_mlp_layered" in lib.nerf_amd_last_error()
+    assert lib.nerf_mlp_forward(f128, p, p, p, 4, 1, p, p, None, None) == UNSUPPORTED
+    assert lib.nerf_mlp_backward(f128, p, p, p, p, 4, 1, p, p, p, p, p, p, p, None) == UNSUPPORTED
+    assert lib.nerf_render_pass(f128, p, p, p, 4, 64, 0, p, 0.1, None, p, None, None, p, p, None, None, None, None) == UNSUPPORTED
+    assert lib.nerf_mlp_packed_bytes(f128) == -1 and lib.nerf_mlp_saved_bytes(f128, 10) == -1
+    sh = net(16, 16, 256, -1, 0, -1, 0)                                            # fused widths, encoders unknown
+    assert lib.nerf_mlp_forward(sh, p, p, p, 4, 0, p, p, None, None) == UNSUPPORTED and b"levels" in lib.nerf_amd_last_error()
+    assert lib.nerf_render_pass(sh, p, p, p, 4, 64, 0, p, 0.1, None, p, None, None, p, p, None, None, None, None) == UNSUPPORTED
+    other = net(39, 15, 256, 6, 1, 2, 1)
+    assert lib.nerf_mlp_forward_bf16(other, p, p, p, 4, p, p, None) == UNSUPPORTED and b"shipped" in lib.nerf_amd_last_error()
+    assert lib.nerf_mlp_packed_bf16_bytes(other) > 0                                # the stream format itself is width-generic
+    bad = net(63, 27, 256, 9, 1, 4, 1)
+    assert lib.nerf_mlp_forward(bad, p, p, p, 4, 1, p, p, None, None) == ARG
+    assert lib.nerf_mlp_layered_forward(bad, p, p, p, 4, p, p, p, 4, None) == ARG
+    assert lib.nerf_shenc(p, 4, 6, p, None) == ARG and lib.nerf_shenc(p, 4, 0, p, None) == ARG
+    assert lib.nerf_shenc_backward(p, p, 4, 9, p, None) == ARG
+    # M = 0: nothing to do, nothing launched
+    assert lib.nerf_mlp_forward(None, p, p, p, 0, 1, p, p, None, None) == OK
+    assert lib.nerf_mlp_layered_forward(f128, p, p, p, 0, p, p, p, 4, None) == OK
+    assert lib.nerf_shenc(p, 0, 4, p, None) == OK and lib.nerf_posenc_backward(p, p, 0, 3, 10, 1, p, None) == OK
+    assert lib.nerf_mlp_forward(None, p, p, p, -1, 1, p, p, None, None) == ARG
