@@ -73,7 +73,17 @@ class RaySamplerBase(object):
         table of volume_renderer.py:171-190 is evaluated inside the kernel instead of being built."""
         k4, focal = self._camera_numbers(camera, project_to_ndc)
         device = _current_device() if device is None else torch.device(device)
-        pix = None if pixel_indices is None else pixel_indices.to(device, torch.int64, non_blocking=True)
+        pix = None
+        if pixel_indices is not None:
+            pix = pixel_indices
+            if not pix.is_cuda and not pix.is_pinned():
+                # the runners hand over a pageable CPU tensor (np.random.choice).  A pageable host-to-device copy
+                # waits for the stream to drain before it starts, i.e. for the previous step's backward pass, and only
+                # then can this step's first kernel be queued; through a pinned staging buffer the copy and everything
+                # behind it is simply queued (32 KB memcpy; the pinned block is recycled by torch's host allocator
+                # once the copy has run)
+                pix = pix.to(torch.int64).pin_memory()
+            pix = pix.to(device, torch.int64, non_blocking=True)
         o, d = ops.generate_rays(camera.img_height, camera.img_width, k4, camera.extrinsic,
                                  project_to_ndc, focal, camera.t_near, device, pix=pix, first=first,
                                  count=count)
