@@ -48,10 +48,15 @@ class NeRF(nn.Module):
 
     # ------------------------------------------------------------------ parameters -> kernel stream
     def _ordered_params(self):
+        """The 22 parameters in state_dict order.  Read through the modules' own dictionaries: nn.Module.__getattr__
+        is the slow path of attribute lookup, and this runs on every forward of a training step (between a .item()
+        and the next kernel launch, with the GPU idle)."""
+        mods = self._modules
         out = []
         for name in _LAYERS:
-            layer = getattr(self, name)
-            out += [layer.weight, layer.bias]
+            params = mods[name]._parameters
+            out.append(params["weight"])
+            out.append(params["bias"])
         return out
 
     def _stream(self):
