@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
     pipe.issue_pos = 0;
     pipe.consumed = 0;
     pipe.n_pairs = BWD_CHUNKS / 2;
+    pipe.skip_pair = -1;
     __syncthreads();
     pipe.issue();
 

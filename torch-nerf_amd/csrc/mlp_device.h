@@ -151,6 +151,8 @@ struct Pipe {
     int issue_pos;         // stream position (in pairs) of the next pair to issue
     unsigned consumed;     // pairs consumed so far
     int n_pairs;
+    int skip_pair;         // stream position the walk jumps over (-1: none): the fc_9 direction pair when the caller
+                           // supplies the per-ray direction contribution itself (never position 0, never the last)
 
     // one of the 16 one-KiB pieces this wave copies per pair (piece 0..7 -> chunk 0, 8..15 -> chunk 1)
     __device__ __forceinline__ void issue_piece(int piece) const {
@@ -161,6 +163,7 @@ struct Pipe {
     __device__ __forceinline__ void issue_done() {
         ++issued;
         issue_pos = (issue_pos + 1 == n_pairs) ? 0 : issue_pos + 1;
+        if (issue_pos == skip_pair) ++issue_pos;
     }
     __device__ __forceinline__ void issue() {
 #pragma unroll

@@ -78,9 +78,15 @@ constexpr int CH_FC5_ENC = 34; // 2        : fc_5[:, 0:63]   (skip connection, p
 constexpr int CH_FC5 = 36;     // 8        : fc_5[:, 63:319]
 constexpr int CH_TRUNK6 = 44;  // 2 x 8    : fc_6, fc_7
 constexpr int CH_FC8 = 60;     // 8        : fc_8 rows 1..256
-constexpr int CH_FC9 = 68;     // 9 (+1)   : fc_9[:, 0:256] then fc_9[:, 256:283] (dir, padded to 32); rows 0..127;
-                               //            chunk 77 is zero filler so that the stream is a whole number of PAIRS
+constexpr int CH_FC9_DIR = 68; // 1 (+1)   : fc_9[:, 256:256+E_d] (direction, padded to 32), rows 0..127; chunk 69 is zero
+                               //            filler so that the stream is a whole number of PAIRS.  The direction goes
+                               //            FIRST: its contribution to the accumulators (bias + 27 fma's, in the k order
+                               //            of the MFMA chain) depends on the ray only, so the fused render pass computes
+                               //            it once per ray, starts fc_9 from that vector and skips this pair -- with
+                               //            bit-identical results (render_fused.hip)
+constexpr int CH_FC9 = 70;     // 8        : fc_9[:, 0:256]; rows 0..127
 constexpr int FWD_CHUNKS = 78;
+constexpr int FC9_DIR_PAIR = CH_FC9_DIR / 2;   // the pair a ray-constant direction lets the kernel skip
 constexpr int64_t FWD_BYTES = (int64_t)CONST_BYTES + (int64_t)FWD_CHUNKS * CHUNK_BYTES;
 
 // ---- transposed stream for the backward dX chain (chunks of W^T: rows = INPUT feature,

@@ -43,10 +43,10 @@ __device__ float forward_chunk_value(const Params &P, int ci, int n, int kk) {
         const int l = 6 + (ci - CH_TRUNK6) / 8, kb = (ci - CH_TRUNK6) % 8;
         return P.w(l, n, 32 * kb + kk);
     }
-    if (ci < CH_FC9) return P.w(8, n + 1, 32 * (ci - CH_FC8) + kk);
+    if (ci < CH_FC9_DIR) return P.w(8, n + 1, 32 * (ci - CH_FC8) + kk);
     if (n >= HALF) return 0.0f;
-    if (ci < CH_FC9 + 8) return P.w(9, n, 32 * (ci - CH_FC9) + kk);
-    if (ci == CH_FC9 + 8) return kk < E_DIR ? P.w(9, n, FEAT + kk) : 0.0f;
+    if (ci == CH_FC9_DIR) return kk < E_DIR ? P.w(9, n, FEAT + kk) : 0.0f;
+    if (ci >= CH_FC9) return P.w(9, n, 32 * (ci - CH_FC9) + kk);
     return 0.0f;  // filler chunk (pairs)
 }
 

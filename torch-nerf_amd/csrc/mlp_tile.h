@@ -30,12 +30,18 @@ enum { IN_ENCODED = 0, IN_SHIPPED = 1, IN_LEVELS = 2 };
 // Inputs of this lane's sample: raw[0..2] position, raw[3..5] direction (IN_ENCODED: read from pos/dir rows mc instead).
 // `after_encode()` runs once the raw inputs are consumed (the caller prefetches the next tile's there).
 // Outputs: sigma and the three colours of sample m, valid in the lanes of both halves.
-template <int INPUT, bool SAVE, class AfterEncode>
+// RAYDIR (render_fused.hip): the direction of this lane's sample is its RAY's, so fc_9's direction contribution was
+// computed once per ray: `fc9_init` points at this lane's ray row of 128 floats (LDS) = fc_9.bias + W9[:, 256:] enc(d),
+// accumulated in the k order of the MFMA chain below -- the accumulators start from it, no direction is encoded, and
+// the direction pair of the stream is neither fetched (Pipe::skip_pair) nor multiplied.  Same bits, 64 MFMAs, one
+// acquire and twelve sincos per sample less.
+template <int INPUT, bool SAVE, bool RAYDIR = false, class AfterEncode>
 __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[6], const float *__restrict__ pos,
                                              const float *__restrict__ dir, int64_t mc, int64_t m, int64_t MP,
                                              int h, Pipe &pipe, const char *lds, const float *cb, const int (&offq)[4],
                                              float *__restrict__ saved, AfterEncode after_encode, Timeline &tl,
-                                             float &sigma_result, float (&y)[3]) {
+                                             float &sigma_result, float (&y)[3], const float *fc9_init = nullptr) {
+    static_assert(!RAYDIR || (!SAVE && INPUT != IN_ENCODED), "ray-constant directions: raw-input inference only");
     constexpr bool ENCODED = INPUT == IN_ENCODED;
     const int E_POS = INPUT == IN_SHIPPED ? DEFAULT_NET.e_pos : net.e_pos;
     const int E_DIR = INPUT == IN_SHIPPED ? DEFAULT_NET.e_dir : net.e_dir;
@@ -60,7 +66,7 @@ __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[
                 const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
                 pe[0][r] = enc_feature<true>(k, raw[0], raw[1], raw[2], E_POS, net.inc_pos);
                 pe[1][r] = enc_feature<true>(32 + k, raw[0], raw[1], raw[2], E_POS, net.inc_pos);
-                de[r] = enc_feature<true>(k, raw[3], raw[4], raw[5], E_DIR, net.inc_dir);
+                if (!RAYDIR) de[r] = enc_feature<true>(k, raw[3], raw[4], raw[5], E_DIR, net.inc_dir);
             }
         } else {
 #pragma unroll
@@ -68,7 +74,7 @@ __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[
                 const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
                 pe[0][r] = enc_feature<false>(k, raw[0], raw[1], raw[2], E_POS, net.inc_pos);
                 pe[1][r] = enc_feature<false>(32 + k, raw[0], raw[1], raw[2], E_POS, net.inc_pos);
-                de[r] = enc_feature<false>(k, raw[3], raw[4], raw[5], E_DIR, net.inc_dir);
+                if (!RAYDIR) de[r] = enc_feature<false>(k, raw[3], raw[4], raw[5], E_DIR, net.inc_dir);
             }
         }
     } else if (__builtin_expect(__any(encoding_needs_exact(raw, L_POS, L_DIR)), 0)) {
@@ -78,7 +84,7 @@ __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[
             const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
             pe[0][r] = enc_feature<true>(k, raw[0], raw[1], raw[2], E_POS);
             pe[1][r] = enc_feature<true>(32 + k, raw[0], raw[1], raw[2], E_POS);
-            de[r] = enc_feature<true>(k, raw[3], raw[4], raw[5], E_DIR);
+            if (!RAYDIR) de[r] = enc_feature<true>(k, raw[3], raw[4], raw[5], E_DIR);
         }
     } else {
         {
@@ -87,7 +93,7 @@ __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[
             table_to_fragment(F, 0, h, pe[0]);
             table_to_fragment(F, 1, h, pe[1]);
         }
-        {
+        if (!RAYDIR) {
             float F[32];
             encode_table<DEFAULT_NET.l_dir, 32>(raw[3], raw[4], raw[5], F);
             table_to_fragment(F, 0, h, de);
@@ -141,23 +147,29 @@ __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[
         }
     }
 
-    // ---- fc_9 on cat([x[:,1:], view_dir]) -- features FIRST (:116-118); fc_8 has no ReLU (:113)
+    // ---- fc_9 on cat([x[:,1:], view_dir]) (:116-118); fc_8 has no ReLU (:113).  The reference's cat puts the features
+    // first; the ORDER OF ACCUMULATION here is bias, direction, features (any order is the same sum up to fp32
+    // rounding; this one lets a ray-constant direction be folded into the starting value, see RAYDIR above)
     NERF_TS();
     {
         const char *w = lds + pipe.acquire();
 #pragma unroll
         for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];
         if (SAVE) save_plane<8>(saved + pl_y8(MP), 256, m, h, act);
-        load_bias<4>(acc, cb + CB_BIAS9, h);
+        if (RAYDIR) {
+            load_bias<4>(acc, fc9_init, h);           // this lane's ray: bias + direction part, as the chain below leaves it
+        } else {
+            load_bias<4>(acc, cb + CB_BIAS9, h);
+            mma_chunk<4, 0, 16>(acc, de, w, offq, &pipe);   // direction chunk + filler chunk (not multiplied)
+            pipe.issue_done();
+            w = lds + pipe.acquire();
+        }
         mma_pair<4>(acc, act[0], act[1], w, offq, pipe);
 #pragma unroll
         for (int pr = 1; pr < 4; ++pr) {
             w = lds + pipe.acquire();
             mma_pair<4>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
         }
-        w = lds + pipe.acquire();  // direction chunk + filler chunk (not multiplied)
-        mma_chunk<4, 0, 16>(acc, de, w, offq, &pipe);
-        pipe.issue_done();
     }
     NERF_TS();
     sigma_pre += __shfl_xor(sigma_pre, 32, WAVE);

@@ -54,9 +54,50 @@ struct FusedArgs {
     int G;                   // rays per group
 };
 
+constexpr int DIRROW = HALF + 32;   // per ray: fc_9 starting values (128) + the encoded direction (32)
+
 __host__ __device__ inline int fused_lds_floats(int G, int S, int Sc, int Sf) {
-    // t: BUNCH rows; sigma G*S, radiance 3*G*S (one group at a time); o,d: 8 per ray (padded); sampling scratch per ray
-    return BUNCH * S + 4 * G * S + 8 * BUNCH + BUNCH * render::hierarchical_scratch_floats(Sc, Sf);
+    // t: BUNCH rows; sigma G*S, radiance 3*G*S (one group at a time); o,d: 8 per ray (padded); sampling scratch per ray;
+    // per ray the fc_9 starting vector + encoded direction
+    return BUNCH * S + 4 * G * S + 8 * BUNCH + BUNCH * render::hierarchical_scratch_floats(Sc, Sf) + BUNCH * DIRROW;
+}
+
+// fc_9's accumulators after the bias and the direction chunk, for ONE ray, exactly as forward_tile's MFMA chain leaves
+// them: v[n] = fma(W[n][k1] e[k1], fma(W[n][k0] e[k0], ...bias[n])) with the k-steps in the order the 32x32x2 MFMAs of
+// mma_chunk take them -- group q, step j multiplies feature 8q + j (lane half 0) and then 8q + j + 4 (lane half 1) --
+// so that the fused pass stays bit-identical to the kernel chain, whose every sample of the ray computes this same
+// vector.  One wavefront per ray: lane k < 32 encodes direction feature k (the same enc_feature / sincos_cw the tile
+// uses), every lane then runs the chain for outputs n = lane and lane + 64 with the weights of the stream's direction
+// chunk (L2-resident; chunk_slot_offset is its swizzle).
+template <int INPUT>
+__device__ __forceinline__ void ray_direction_row(const Net &net, const char *packed, const float *cb, const float *od,
+                                                  int lane, float *row) {
+    float *enc = row + HALF;
+    const int e_dir = INPUT == IN_SHIPPED ? DEFAULT_NET.e_dir : net.e_dir;
+    const int inc = INPUT == IN_SHIPPED ? 1 : net.inc_dir;
+    const int l_dir = INPUT == IN_SHIPPED ? DEFAULT_NET.l_dir : net.l_dir;
+    const float d0 = od[4], d1 = od[5], d2 = od[6];
+    const float big = fmaxf(fmaxf(fabsf(d0), fabsf(d1)), fabsf(d2));
+    const bool exact = !(ldexpf(big, l_dir - 1) < 30000.0f);     // wave-uniform (one ray per wavefront)
+    if (lane < 32)
+        enc[lane] = exact ? enc_feature<true>(lane, d0, d1, d2, e_dir, inc) : enc_feature<false>(lane, d0, d1, d2, e_dir, inc);
+    render::wave_fence();
+    const char *chunk = packed + CONST_BYTES + (size_t)CH_FC9_DIR * CHUNK_BYTES;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int n = lane + 64 * half;
+        float v = cb[CB_BIAS9 + n];
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int k = 8 * q + j + 4 * hh;
+                    const float w = *reinterpret_cast<const float *>(chunk + chunk_slot_offset(n, k >> 2) + 4 * (k & 3));
+                    v = fmaf(w, enc[k], v);
+                }
+        row[n] = v;
+    }
 }
 
 template <int INPUT>
@@ -76,6 +117,7 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
     float *od_rows = rad_rows + 3 * GS;         // [BUNCH][8]: o, d
     float *scratch = od_rows + 8 * BUNCH;       // [BUNCH][hierarchical_scratch_floats]
     const int scratch_stride = render::hierarchical_scratch_floats(a.Sc, a.Sf);
+    float *dir_rows = scratch + BUNCH * scratch_stride;   // [BUNCH][DIRROW]: fc_9 starting vector + encoded direction
 
     for (int e = tid; e < CONST_FLOATS / 4; e += 256)
         reinterpret_cast<f32x4 *>(cb)[e] = reinterpret_cast<const f32x4 *>(a.packed)[e];
@@ -92,6 +134,7 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
     pipe.issue_pos = 0;
     pipe.consumed = 0;
     pipe.n_pairs = FWD_CHUNKS / 2;
+    pipe.skip_pair = FC9_DIR_PAIR;     // the direction's contribution comes per ray (ray_direction_row)
     __syncthreads();
     pipe.issue();
 
@@ -124,6 +167,8 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
                 if (lane < 8) od_rows[8 * wave + lane] = 0.0f;
                 for (int s = lane; s < S; s += WAVE) t_row[s] = 0.0f;
             }
+            render::wave_fence();   // this wavefront's own o, d row is complete
+            ray_direction_row<INPUT>(a.net, a.packed, cb, od_rows + 8 * wave, lane, dir_rows + wave * DIRROW);
         }
         RD_STAMP();
         __syncthreads();   // rows of this bunch are complete; the previous bunch's last integration has finished
@@ -146,8 +191,8 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
                     }
                 }
                 float sigma, y[3];
-                forward_tile<INPUT, false>(a.net, raw, nullptr, nullptr, 0, 0, 0, h, pipe, lds, cb, offq, nullptr,
-                                           []() {}, tl, sigma, y);
+                forward_tile<INPUT, false, true>(a.net, raw, nullptr, nullptr, 0, 0, 0, h, pipe, lds, cb, offq, nullptr,
+                                                 []() {}, tl, sigma, y, dir_rows + r * DIRROW);
                 if (h == 0) {
                     sig_rows[ml] = sigma;
                     rad_rows[3 * ml + 0] = y[0];
