@@ -180,7 +180,11 @@ class FusedAdam(torch.optim.Optimizer):
                         local[first:last] = [False] * (last - first)
                     else:
                         arena.G[a:b].copy_(g)
-                arena.G_flags[arena.n:].copy_(torch.tensor([float(x) for x in local]), non_blocking=False)
+                if all(local):       # the usual step: one fill kernel, no host-to-device copy (a pageable copy would
+                    arena.G_flags[arena.n:].fill_(1.0)          # drain the stream and stall the host behind the backward)
+                else:
+                    arena.G_flags[arena.n:].copy_(torch.tensor([float(x) for x in local]).pin_memory(),
+                                                  non_blocking=True)
                 dist.all_reduce(arena.G_flags, op=dist.ReduceOp.SUM, group=self._process_group)
                 has = local if all(local) else [x > 0.0 for x in arena.G_flags[arena.n:].tolist()]
                 i = 0
