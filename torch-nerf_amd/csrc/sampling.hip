@@ -47,16 +47,20 @@ __global__ __launch_bounds__(WAVE) void stratified_kernel(const float *ray_o, co
     }
 }
 
-__global__ __launch_bounds__(WAVE) void hierarchical_kernel(
+constexpr int HIER_RAYS_PER_BLOCK = 4;   // one wavefront per ray, four rays per workgroup (like the integral kernels)
+
+__global__ __launch_bounds__(HIER_RAYS_PER_BLOCK * WAVE) void hierarchical_kernel(
     const float *ray_o, const float *ray_d, int64_t n, int Sc, int Sf, const float *t_bins, float ps,
     float *weights, const float *u1, const float *u2, const float *u3, int64_t *bin_idx, float *t_out,
-    float *pts, float *dirs, float *delta) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *pts, float *dirs, float *delta, int floats_per_ray) {
+    extern __shared__ __attribute__((aligned(16))) float sm_all[];
     const int S = Sc + Sf;
+    const int wave = threadIdx.x / WAVE, rays_per_block = blockDim.x / WAVE;
+    float *sm = sm_all + wave * floats_per_ray;
     float *t_srt = sm;           // S sorted positions; the per-ray scratch rows follow
     float *scratch = sm + ((S + 3) & ~3);
-    const int lane = threadIdx.x;
-    for (int64_t ray = blockIdx.x; ray < n; ray += gridDim.x) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (int64_t ray = (int64_t)blockIdx.x * rays_per_block + wave; ray < n; ray += (int64_t)gridDim.x * rays_per_block) {
         wave_fence();   // the previous ray's row has been written out
         render::hierarchical_ray(lane, Sc, Sf, t_bins, ps, weights + ray * Sc, u1 + ray * Sc, u2 + ray * Sf,
                                  u3 + ray * Sf, bin_idx ? bin_idx + ray * Sf : nullptr, scratch, t_srt);
@@ -97,9 +101,11 @@ NERF_API int nerf_sample_hierarchical(const float *ray_o, const float *ray_d, in
     const size_t floats = (size_t)((Sc + Sf + 3) & ~3) + (size_t)render::hierarchical_scratch_floats(Sc, Sf);
     if (floats > (size_t)MAX_LDS_FLOATS)
         return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_sample_hierarchical: Sc+Sf too large for LDS");
-    const unsigned grid = (unsigned)(n < 1048576 ? n : 1048576);
-    hipLaunchKernelGGL(hierarchical_kernel, dim3(grid), dim3(WAVE), floats * sizeof(float),
-                       nerf::as_stream(stream), ray_o, ray_d, n, Sc, Sf, t_bins, partition_size, weights,
-                       u1, u2, u3, bin_idx, t, pts, dirs, delta);
+    const int rpb = HIER_RAYS_PER_BLOCK * floats <= (size_t)MAX_LDS_FLOATS ? HIER_RAYS_PER_BLOCK : 1;   // very long rows: one ray per workgroup
+    const int64_t blocks = (n + rpb - 1) / rpb;
+    const unsigned grid = (unsigned)(blocks < 1048576 ? blocks : 1048576);
+    hipLaunchKernelGGL(hierarchical_kernel, dim3(grid), dim3(rpb * WAVE),
+                       rpb * floats * sizeof(float), nerf::as_stream(stream), ray_o, ray_d, n, Sc, Sf,
+                       t_bins, partition_size, weights, u1, u2, u3, bin_idx, t, pts, dirs, delta, (int)floats);
     return nerf::check_launch("nerf_sample_hierarchical");
 }
