@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 2
+#define NERF_AMD_ABI_VERSION 3
 
 enum {
     NERF_OK = 0,
@@ -139,13 +139,16 @@ int nerf_mlp_forward_bf16(const nerf_net_t *net, const void *packed_bf16, const 
 
 /* ---- a13 (MLP part): gradients of all 22 parameter tensors (autograd in the
  * reference, entered at runners/train.py:215).  g_params (param_count floats, same
- * layout as `params`) is OVERWRITTEN.  workspace: nerf_mlp_backward_workspace_bytes(net, M). */
+ * layout as `params`) is OVERWRITTEN.  workspace: nerf_mlp_backward_workspace_bytes(net, M).
+ * g_pos (M,pos_dim) / g_view_dir (M,view_dir_dim), each optional (NULL): the gradients autograd returns for the two
+ * ENCODED inputs of NeRF.forward (R/network/nerf.py:102, :108, :116) -- whatever `encoded` says; a caller that fed
+ * raw points chains nerf_posenc_backward behind them.  Asking for either adds three thin GEMMs to the dX chain. */
 int64_t nerf_mlp_backward_workspace_bytes(const nerf_net_t *net, int64_t M);
 int nerf_mlp_backward(const nerf_net_t *net, const void *packed, const float *params, const float *pos,
                       const float *view_dir, int64_t M, int encoded, const float *sigma,
                       const float *rgb, const void *saved, const float *g_sigma,
-                      const float *g_rgb, float *g_params, void *workspace,
-                      nerf_stream_t stream);
+                      const float *g_rgb, float *g_params, float *g_pos, float *g_view_dir,
+                      void *workspace, nerf_stream_t stream);
 
 /* ---- a10 + a13, NERF_PATH_LAYERED (any pos_dim / view_dir_dim / feat_dim): NeRF.forward on PRE-ENCODED inputs
  * pos (M,pos_dim), view_dir (M,view_dir_dim) as one fp32-MFMA GEMM launch per layer (bias, ReLU, sigmoid and the

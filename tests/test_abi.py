@@ -21,7 +21,7 @@ def test_library_builds_loads_and_exports_header():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nerf_amd_abi_version() == 2
+    assert lib.nerf_amd_abi_version() == 3
     assert lib.nerf_mlp_param_count(None) == 595844
     # sizes only -- no compute without a GPU
     assert lib.nerf_mlp_packed_bytes(None) == 13312 + (78 + 68) * 32768

@@ -80,6 +80,72 @@ def test_mlp_backward_vs_oracle_full_tensor(oracle, M):
     assert_grads_match_given_masks(got, ref, synth.split_flat_params, f"M={M} ")
 
 
+@pytest.mark.parametrize("M,levels", [(1, (10, 4, True)), (129, (10, 4, True)), (5000, (10, 4, True)),
+                                      (1000, (6, 2, False)), (777, (4, 4, True))])
+def test_fused_input_gradients_vs_oracle(oracle, M, levels):
+    """g_pos / g_view_dir out of the fused dX chain (the three thin GEMMs of csrc/mlp_backward.hip, IG variant) --
+    what autograd returns for the two inputs of NeRF.forward (nerf.py:102, :108, :116) -- every element against the
+    CPU oracle under the kernel's own ReLU decisions, together with the parameter gradients of the same launch (which
+    must equal the plain chain's bit for bit: same kernels on the same planes)."""
+    from helpers import assert_grads_match_given_masks, fused_masks
+    lp, ld, inc = levels
+    e_p, e_d = 6 * lp + 3 * inc, 6 * ld + 3 * inc
+    rng = np.random.RandomState(M + 17)
+    pts = rng.uniform(-3, 3, (M, 3)).astype(np.float32)
+    dirs = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    gs = rng.standard_normal(M).astype(np.float32)
+    gc = rng.standard_normal((M, 3)).astype(np.float32)
+    flat = synth.nerf_flat_params(seed=13, pos_dim=e_p, view_dir_dim=e_d, sigma_bias=0.3, sigma_gain=20.0)
+    pe, de = oracle.posenc(pts, lp, inc), oracle.posenc(dirs, ld, inc)
+    spec = ops.Net(e_p, e_d, 256, lp, inc, ld, inc)
+    fp = dev(flat)
+    packed = ops.mlp_pack(fp, spec)
+    sigma, rgb, saved = ops.mlp_forward(packed, dev(pe), dev(de), encoded=True, save=True, net=spec)
+    plain = ops.mlp_backward(packed, fp, dev(pe), dev(de), True, sigma, rgb, saved, dev(gs), dev(gc), net=spec)
+    got, g_pos, g_dir = ops.mlp_backward(packed, fp, dev(pe), dev(de), True, sigma, rgb, saved, dev(gs), dev(gc),
+                                         net=spec, want_pos=True, want_dir=True)
+    assert torch.equal(got, plain)
+    assert tuple(g_pos.shape) == (M, e_p) and tuple(g_dir.shape) == (M, e_d)
+    masks = fused_masks(saved, sigma, M)
+    _, _, _, own = oracle.mlp_backward_ex(flat, pe, de, gs, gc, want_inputs=False, want_masks=True)
+    assert (masks != own).mean() < 1e-5
+    ref, ref_pos, ref_dir, _ = oracle.mlp_backward_ex(flat, pe, de, gs, gc, want_inputs=True, force_masks=masks)
+    split = lambda f: synth.split_flat_params(f, e_p, e_d, 256)
+    assert_grads_match_given_masks(got.cpu().numpy(), ref, split, f"M={M} ")
+    for name, a, b in (("g_pos", g_pos.cpu().numpy(), ref_pos), ("g_view_dir", g_dir.cpu().numpy(), ref_dir)):
+        rms = np.sqrt(np.mean(b.astype(np.float64) ** 2)) + 1e-30
+        bad = np.abs(a - b) > 2e-5 * np.abs(b) + 2e-5 * rms
+        assert not bad.any(), f"{name}: {bad.sum()} of {bad.size} beyond the bound, worst {np.abs(a - b).max() / rms:.2e} rms"
+    # one side only: the other pointer NULL
+    _, only_pos, none_dir = ops.mlp_backward(packed, fp, dev(pe), dev(de), True, sigma, rgb, saved, dev(gs), dev(gc),
+                                             net=spec, want_pos=True)
+    assert none_dir is None and torch.equal(only_pos, g_pos)
+
+
+def test_raw_point_gradients_through_the_fused_query(golden):
+    """PrimitiveCube.query_points on raw points that require grad (the reference's autograd reaches them through
+    cube.py:59-72): fused record forward -> IG dX chain -> reverse of PositionalEncoder.encode, against fixture F11's
+    gradients w.r.t. the raw points / directions captured from the reference."""
+    from helpers import NET_VARIANTS, variant_params
+    g = golden("f11_net_variants")
+    for tag in ("l6_l2", "l4_l4", "l10_l4_noinput"):
+        lp, ld, inc, feat = NET_VARIANTS[tag]
+        flat, dims = variant_params(g, tag)
+        net = network.NeRF(*dims)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.split_flat_params(flat, *dims).items()})
+        net = net.cuda()
+        cube = scene.PrimitiveCube(net, {"coord_enc": PositionalEncoder(3, lp, inc), "dir_enc": PositionalEncoder(3, ld, inc)})
+        M = g["pts"].shape[0]
+        pts = dev(g["pts"]).view(M // 4, 4, 3).requires_grad_(True)
+        dirs = dev(g["dirs"]).view(M // 4, 4, 3).requires_grad_(True)
+        sigma, rgb = cube.query_points(pts, dirs)
+        np.testing.assert_allclose(sigma.detach().cpu().numpy().reshape(-1), g[tag + "_sigma"], rtol=0, atol=1e-5)
+        ((sigma.reshape(-1) * dev(g["g_sigma"])).sum() + (rgb.reshape(-1, 3) * dev(g["g_rgb"])).sum()).backward()
+        check_grad_digest(flat_grad(net), g, tag + "_grad_", rtol=2e-4, atol_scale=2e-3, dims=dims)
+        for got, want in ((pts.grad.reshape(M, 3), g[tag + "_g_pts"]), (dirs.grad.reshape(M, 3), g[tag + "_g_dirs"])):
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-5 * np.abs(want).max())
+
+
 def test_autograd_function_paths(golden):
     """NeRF.forward (encoded inputs) and forward_fused (raw inputs) give the same gradients."""
     g = golden("f5_mlp")

@@ -41,6 +41,13 @@ __device__ __forceinline__ float masked(const u32x4 &mk, int fb, int r, float v)
     return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
 }
 
+// IG: also the gradients w.r.t. the two (encoded) inputs of the network -- what autograd returns for `pos` and
+// `view_dir` of NeRF.forward (nerf.py:102, :108, :116) -- from three extra pairs of the transposed stream:
+//   g_view_dir = dY9 W9[:, 256:]           behind the fc_9 stage (accumulator block: act[4..7] are idle there)
+//   g_pos      = dY0 W_in + dY5 W5[:, :E_p]   in the epilogue (dY5 re-read from its plane; autograd adds the two too)
+// +576 MFMAs per 32 samples (+6.6 %).  Both leave as TF planes like every other gradient plane (the chain has no
+// registers left for row-major addresses); input_grad_rows_kernel writes the callers' row-major (M, E_p) / (M, E_d).
+template <bool IG>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restrict__ packed, int64_t M,
                                                              const float *__restrict__ sigma,
                                                              const float *__restrict__ rgb,
@@ -71,10 +78,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
     pipe.lds_wave =
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 8192u;
     pipe.issued = 0;
-    pipe.issue_pos = 0;
+    pipe.issue_pos = IG ? 0 : BW_FC9T / 2;   // the first pair of the walk
     pipe.consumed = 0;
     pipe.n_pairs = BWD_CHUNKS / 2;
-    pipe.skip_pair = -1;
+    pipe.skip_mask = IG ? 0ull : BWD_INPUT_GRAD_PAIRS;
     __syncthreads();
     pipe.issue();
 
@@ -96,6 +103,15 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         const bool valid = m < M;
         const int64_t mc = valid ? m : M - 1;
 
+        // (IG: hipcc hoists the ~50 per-lane LDS addresses of the constant-block reads below out of the tile loop
+        // and, with the chain's 500 registers taken, spills them; an offset it cannot see through keeps the address
+        // arithmetic -- a handful of v_add per tile -- inside the loop.  The plain chain is left as it was tuned.)
+        const float *cbt = cb;
+        if (IG) {
+            int zero;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+            cbt = cb + zero;
+        }
         // fc_out + sigmoid (nerf.py:119): d y10 = g_rgb * rgb * (1 - rgb)
         float gy[3];
 #pragma unroll
@@ -128,9 +144,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int k0 = 32 * fb + 8 * q + 4 * h;
-                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(cb + CB_WOUT + k0);
-                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(cb + CB_WOUT + HALF + k0);
-                    const f32x4 w2 = *reinterpret_cast<const f32x4 *>(cb + CB_WOUT + 2 * HALF + k0);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(cbt + CB_WOUT + k0);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(cbt + CB_WOUT + HALF + k0);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4 *>(cbt + CB_WOUT + 2 * HALF + k0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v = fmaf(w2[j], gy[2], fmaf(w1[j], gy[1], w0[j] * gy[0]));
@@ -138,9 +154,15 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
                     }
                 }
         }
-        save_plane<4>(dy + dy9_plane(MP), 128, m, h, act);
+        save_plane<4, true>(dy + dy9_plane(MP), 128, m, h, act);
         mk = masks[(int64_t)7 * MP * 2 + 2 * m + h];   // for the seam of l = 7
 
+        if (IG) {   // g_view_dir = W9[:, 256:]^T dY9 (nerf.py:116: the direction is the tail of fc_9's input)
+            mma_slots<1, 4, 0, 16, true>(acc, act, w, offq, &pipe);
+            pipe.issue_done();
+            save_plane<1, true>(dy + gd_plane(MP), 32, m, h, acc);
+            w = lds + pipe.acquire();
+        }
         // ---- d y8[1:257] = W9[:, 0:256]^T dY9   (fc_9 input is cat([x[:,1:], dir]): nerf.py:116)
         mma_pair<8, true>(acc, act[0], act[1], w, offq, pipe);   // accumulators start from C = 0
         w = lds + pipe.acquire();
@@ -164,13 +186,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
                     for (int r = 0; r < 16; ++r) act[fb][r] = masked(mk, fb, r, acc[fb][r]);
                 mk = masks[(int64_t)(l - 1) * MP * 2 + 2 * m + h];   // h(l-1): next seam (l = 1: the dY0 epilogue)
             }
-            save_plane<8>(dy + dy_plane(MP, l), 256, m, h, act);
+            save_plane<8, true>(dy + dy_plane(MP, l), 256, m, h, act);
             if (l == 8) {  // the density row of fc_8 contributes w8[0, k] * d y8[0]
 #pragma unroll
                 for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 wv = *reinterpret_cast<const f32x4 *>(cb + CB_W8ROW0 + 32 * fb + 8 * q + 4 * h);
+                        const f32x4 wv = *reinterpret_cast<const f32x4 *>(cbt + CB_W8ROW0 + 32 * fb + 8 * q + 4 * h);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[fb][4 * q + j] = wv[j] * dsig;
                     }
@@ -192,7 +214,27 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
             for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) act[fb][r] = masked(mk, fb, r, acc[fb][r]);
-            save_plane<8>(dy + dy_plane(MP, 0), 256, m, h, act);
+            save_plane<8, true>(dy + dy_plane(MP, 0), 256, m, h, act);
+        }
+        if (IG) {   // g_pos = W_in^T dY0 (nerf.py:102) + W5[:, :E_p]^T dY5 (the skip connection, :108: pos first)
+            w = lds + pipe.acquire();
+            mma_slots<2, 4, 0, 16, true>(acc, act, w, offq, &pipe);
+            mma_slots<2, 4>(acc, act + 4, w + CHUNK_BYTES, offq);
+            pipe.issue_done();
+            // dY5 back from its plane: every lane re-reads the 32 groups it stored four layers ago (save_plane's slots)
+            const float *p5 = dy + dy_plane(MP, 5) + (m - i) * 256;
+#pragma unroll
+            for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(p5 + (fb * 4 + q) * 256 + 4 * ((2 * i + h) ^ (2 * q)));
+                    act[fb][4 * q + 0] = v.x; act[fb][4 * q + 1] = v.y; act[fb][4 * q + 2] = v.z; act[fb][4 * q + 3] = v.w;
+                }
+            w = lds + pipe.acquire();
+            mma_slots<2, 4, 0, 16>(acc, act, w, offq, &pipe);
+            mma_slots<2, 4>(acc, act + 4, w + CHUNK_BYTES, offq);
+            pipe.issue_done();
+            save_plane<2, true>(dy + gp_plane(MP), 64, m, h, acc);
         }
     }
 #pragma unroll
@@ -203,6 +245,25 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         if (lane == 0) bias_partial[((int64_t)blockIdx.x * 4 + wave) * 4 + c] = v;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// TF planes of the input-gradient dX chain -> the callers' row-major tensors (HBM-bound, 0.4 KB/sample):
+//   g_pos[m][k] = GP[m][k] (k < E_p),  g_dir[m][k] = GD[m][k] (k < E_d)
+__global__ void input_grad_rows_kernel(const float *__restrict__ dy, int64_t M, int e_pos, int e_dir,
+                                       float *__restrict__ g_pos, float *__restrict__ g_dir) {
+    const int64_t MP = padded_rows(M);
+    const int64_t total = M * (int64_t)(e_pos + e_dir);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < M * e_pos) {
+            const int64_t m = e / e_pos;
+            const int k = (int)(e - m * e_pos);
+            if (g_pos) g_pos[e] = dy[gp_plane(MP) + tf_offset(64, m, k)];
+        } else {
+            const int64_t e2 = e - M * e_pos, m = e2 / e_dir;
+            const int k = (int)(e2 - m * e_dir);
+            if (g_dir) g_dir[e2] = dy[gd_plane(MP) + tf_offset(32, m, k)];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -687,23 +748,26 @@ NERF_API int64_t nerf_mlp_backward_workspace_bytes(const nerf_net_t *net, int64_
 NERF_API int nerf_mlp_backward(const nerf_net_t *net_abi, const void *packed, const float *params, const float *pos,
                                const float *view_dir, int64_t M, int encoded, const float *sigma,
                                const float *rgb, const void *saved, const float *g_sigma, const float *g_rgb,
-                               float *g_params, void *workspace, nerf_stream_t stream) {
+                               float *g_params, float *g_pos, float *g_view_dir, void *workspace,
+                               nerf_stream_t stream) {
     (void)params; (void)pos; (void)view_dir; (void)encoded;  // the saved record holds the encodings
     mlp::Net net;
     if (int rc = nerf::fused_net(net_abi, net, "nerf_mlp_backward")) return rc;
     NERF_REQUIRE(M >= 0, "nerf_mlp_backward: negative M");
     NERF_REQUIRE(g_params, "nerf_mlp_backward: null g_params");
     hipStream_t s = nerf::as_stream(stream);
-    if (M == 0) {
+    if (M == 0) {   // (g_pos / g_view_dir have no rows)
         if (hipMemsetAsync(g_params, 0, sizeof(float) * net.param_count(), s) != hipSuccess)
             return nerf::check_launch("nerf_mlp_backward: memset");
         return NERF_OK;
     }
     NERF_REQUIRE(packed && sigma && rgb && saved && g_sigma && g_rgb && workspace,
                  "nerf_mlp_backward: null pointer");
-    static nerf::DeviceMask configured_dx{0}, configured_dw{0};
-    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_dx_kernel), mlp::LDS_BYTES,
-                                          configured_dx, "nerf_mlp_backward: LDS attribute (dX)"))
+    static nerf::DeviceMask configured_dx[2] = {{0}, {0}}, configured_dw{0};
+    const bool input_grads = g_pos || g_view_dir;
+    auto dx_kernel = input_grads ? mlp_bwd_dx_kernel<true> : mlp_bwd_dx_kernel<false>;
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(dx_kernel), mlp::LDS_BYTES,
+                                          configured_dx[input_grads], "nerf_mlp_backward: LDS attribute (dX)"))
         return rc;
     if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_dw_kernel), DW_LDS_BYTES,
                                           configured_dw, "nerf_mlp_backward: LDS attribute (dW)"))
@@ -718,10 +782,16 @@ NERF_API int nerf_mlp_backward(const nerf_net_t *net_abi, const void *packed, co
 
     const int64_t ntiles = MP / mlp::TILE_SAMPLES;
     const unsigned dx_grid = (unsigned)(ntiles < cus ? ntiles : (cus < 1024 ? cus : 1024));
-    hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(dx_grid), dim3(256), mlp::LDS_BYTES, s,
+    hipLaunchKernelGGL(dx_kernel, dim3(dx_grid), dim3(256), mlp::LDS_BYTES, s,
                        static_cast<const char *>(packed), M, sigma, rgb, g_sigma, g_rgb, sv, dy, bias_partial);
     int rc = nerf::check_launch("nerf_mlp_backward: dx chain");
     if (rc != NERF_OK) return rc;
+    if (input_grads) {
+        const int64_t total = M * (int64_t)(net.e_pos + net.e_dir);
+        hipLaunchKernelGGL(input_grad_rows_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)),
+                           dim3(256), 0, s, static_cast<const float *>(dy), M, net.e_pos, net.e_dir, g_pos, g_view_dir);
+        if ((rc = nerf::check_launch("nerf_mlp_backward: input gradient rows")) != NERF_OK) return rc;
+    }
     // NERF_DW_TIMING=<file>: debugging aid, dumps per-workgroup durations of the dW kernel (syncs!)
     const char *timing_path = getenv("NERF_DW_TIMING");
     unsigned long long *clocks = nullptr;

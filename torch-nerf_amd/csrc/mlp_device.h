@@ -151,8 +151,11 @@ struct Pipe {
     int issue_pos;         // stream position (in pairs) of the next pair to issue
     unsigned consumed;     // pairs consumed so far
     int n_pairs;
-    int skip_pair;         // stream position the walk jumps over (-1: none): the fc_9 direction pair when the caller
-                           // supplies the per-ray direction contribution itself (never position 0, never the last)
+    unsigned long long skip_mask;   // bit p set: the walk jumps over stream position p (issue_pos starts at the first
+                           // position that is not skipped) -- the fc_9
+                           // direction pair when the caller supplies the per-ray direction contribution itself
+                           // (render_fused.hip), the input-gradient pairs of the transposed stream when the dX chain
+                           // is not asked for them (mlp_backward.hip)
 
     // one of the 16 one-KiB pieces this wave copies per pair (piece 0..7 -> chunk 0, 8..15 -> chunk 1)
     __device__ __forceinline__ void issue_piece(int piece) const {
@@ -162,8 +165,9 @@ struct Pipe {
     }
     __device__ __forceinline__ void issue_done() {
         ++issued;
-        issue_pos = (issue_pos + 1 == n_pairs) ? 0 : issue_pos + 1;
-        if (issue_pos == skip_pair) ++issue_pos;
+        do {
+            issue_pos = (issue_pos + 1 == n_pairs) ? 0 : issue_pos + 1;
+        } while ((skip_mask >> issue_pos) & 1ull);
     }
     __device__ __forceinline__ void issue() {
 #pragma unroll
@@ -235,6 +239,42 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, con
     }
 }
 
+// The same for a SLOT-MAJOR chunk (mlp_layout.h, input-gradient pairs of the transposed stream): eight 4-KiB slots, slot
+// kb * NFB + fb = rows 32 fb .. 32 fb + 31 of the (thin) output x the 32 k-values of operand b[kb], NKB * NFB <= 8:
+//   acc[fb] += sum over kb of W_slot(kb, fb) . b[kb]
+template <int NFB, int NKB, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false>
+__device__ __forceinline__ void mma_slots(f32x16 *acc, const f32x16 *b, const char *chunk, const int (&offq)[4],
+                                          const Pipe *pipe = nullptr) {
+    static_assert(NFB * NKB <= 8, "a chunk holds eight slots");
+    constexpr int GROUPS = 4 * NFB * NKB, EVERY = N_PIECES > 0 ? GROUPS / N_PIECES : 1;
+    const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)chunk;
+    unsigned addr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) addr[q] = base + (unsigned)offq[q];
+    f32x4 abuf[2];
+    abuf[0] = lds_read_fragment(addr[0], 0);
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        const int kb = g / (4 * NFB), q = (g / NFB) % 4, fb = g % NFB;
+        lds_fragments_ready();
+        if (g + 1 < GROUPS) {
+            const int g1 = g + 1, kb1 = g1 / (4 * NFB), q1 = (g1 / NFB) % 4, fb1 = g1 % NFB;
+            abuf[g1 & 1] = lds_read_fragment(addr[q1], (kb1 * NFB + fb1) * 4096);
+        }
+        const f32x4 a = abuf[g & 1];
+        if (FRESH && kb == 0 && q == 0) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[kb][4 * q + 0], zero, 0, 0, 0);
+        } else {
+            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[kb][4 * q + 0], acc[fb], 0, 0, 0);
+        }
+        acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[kb][4 * q + 1], acc[fb], 0, 0, 0);
+        if (N_PIECES > 0 && g % EVERY == 0 && g / EVERY < N_PIECES) pipe->issue_piece(FIRST_PIECE + g / EVERY);
+        acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[kb][4 * q + 2], acc[fb], 0, 0, 0);
+        acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[kb][4 * q + 3], acc[fb], 0, 0, 0);
+    }
+}
+
 // One pipeline step: both chunks of the acquired pair.  The next pair's 16 DMA pieces are all
 // issued during the FIRST chunk, so the youngest of them still has a whole chunk of MFMAs
 // (8 k cycles) to land before the next acquire waits for it.
@@ -297,7 +337,10 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[8], const float *bias, i
 // (finite) values of the clamped lane.  The backward GEMMs stay exact because the GRADIENT planes hold exact
 // zeros there (upstream gradients of padded lanes are zero), so a padded row contributes 0 * finite = 0 to
 // every sum.
-template <int NFB>
+// PAD: every store is followed by the two wait states gfx950 wants between a wide VMEM store and a VALU write of its
+// data registers -- hipcc pads its own stores but cannot see these; kernels whose register allocation is tight enough
+// to reuse a data register at once (the input-gradient dX chain: found by scripts/audit_asm_loads.py) ask for it.
+template <int NFB, bool PAD = false>
 __device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, int h, const f32x16 *blk) {
     const int i = (int)(m & 31);
     const uint64_t tile_addr = reinterpret_cast<uint64_t>(plane + (m - i) * width);
@@ -332,6 +375,7 @@ __device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, i
                              :
                              : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024)
                              : "memory");
+            if (PAD) asm volatile("s_nop 1");
         }
     }
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const Net net, cons
     pipe.issue_pos = 0;
     pipe.consumed = 0;
     pipe.n_pairs = FWD_CHUNKS / 2;
-    pipe.skip_pair = -1;
+    pipe.skip_mask = 0;
     __syncthreads();
     pipe.issue();
 

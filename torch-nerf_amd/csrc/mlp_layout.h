@@ -90,13 +90,25 @@ constexpr int FC9_DIR_PAIR = CH_FC9_DIR / 2;   // the pair a ray-constant direct
 constexpr int64_t FWD_BYTES = (int64_t)CONST_BYTES + (int64_t)FWD_CHUNKS * CHUNK_BYTES;
 
 // ---- transposed stream for the backward dX chain (chunks of W^T: rows = INPUT feature,
-// k = output feature), appended after the forward stream.
-constexpr int BW_FC9T = 0;     // 4 chunks : fc_9[:, 0:256]^T     (rows 256 inputs, k = 128 outputs)
-constexpr int BW_FC8T = 4;     // 8        : fc_8[1:257, :]^T
-constexpr int BW_FC7T = 12;    // 8, then fc_6^T at 20
-constexpr int BW_FC5T = 28;    // 8        : fc_5[:, 63:319]^T
-constexpr int BW_FC4T = 36;    // 8 each: fc_4^T, fc_3^T, fc_2^T, fc_1^T
-constexpr int BWD_CHUNKS = 68;
+// k = output feature), appended after the forward stream.  Three pairs serve the gradients w.r.t. the network's two
+// INPUTS (nerf.py:102, :108, :116: autograd's g_pos, g_view_dir); a dX chain that is not asked for them skips those
+// pairs (BWD_INPUT_GRAD_PAIRS -> Pipe::skip_mask).  They are "slot-major": 16 slots of 4 KiB per pair, slot =
+// [32 input features x 32 output features] in the row format of a chunk's 32-row block:
+//   fc_5[:, :E_p]^T / fc_in^T : slot 2 kb + fb = input block fb (0..1) x output block kb (0..7)
+//   fc_9[:, 256:]^T           : slot kb        = the direction block x output block kb (0..3); slots 4..15 zero
+constexpr int BW_DIRT = 0;     // 2 (slot-major)  : fc_9[:, 256:256+E_d]^T      -> g_view_dir (FIRST: the accumulators are idle)
+constexpr int BW_FC9T = 2;     // 4 chunks : fc_9[:, 0:256]^T     (rows 256 inputs, k = 128 outputs)
+constexpr int BW_FC8T = 6;     // 8        : fc_8[1:257, :]^T
+constexpr int BW_FC7T = 14;    // 8, then fc_6^T at 22
+constexpr int BW_FC5T = 30;    // 8        : fc_5[:, E_p:E_p+256]^T
+constexpr int BW_FC4T = 38;    // 8 each: fc_4^T, fc_3^T, fc_2^T, fc_1^T
+constexpr int BW_FCINT = 70;   // 2 (slot-major)  : fc_in^T                     -> g_pos (fc_in's share)
+constexpr int BW_FC5POST = 72; // 2 (slot-major)  : fc_5[:, 0:E_p]^T            -> g_pos (the skip connection's share; in the
+                               //                   epilogue, from the dY5 plane: inside the layer loop the extra block costs
+                               //                   hipcc its register allocation -- 52 spills)
+constexpr int BWD_CHUNKS = 74;
+constexpr unsigned long long BWD_INPUT_GRAD_PAIRS =
+    (1ull << (BW_DIRT / 2)) | (1ull << (BW_FC5POST / 2)) | (1ull << (BW_FCINT / 2));
 constexpr int64_t BWD_OFFSET = FWD_BYTES;
 constexpr int64_t PACKED_BYTES = FWD_BYTES + (int64_t)BWD_CHUNKS * CHUNK_BYTES;
 
@@ -152,7 +164,11 @@ __host__ __device__ constexpr int64_t dy9_plane(int64_t MP) { return MP * 256 * 
 __host__ __device__ constexpr int64_t dsig_plane(int64_t MP) { return MP * (256 * 9 + 128); }
 //   GY              : grad w.r.t. the three pre-sigmoid colours, [sample][4] (the 4th float is zero) (4/sample)
 __host__ __device__ constexpr int64_t gy_plane(int64_t MP) { return MP * (256 * 9 + 128 + 1); }
-constexpr int DY_FLOATS_PER_SAMPLE = 256 * 9 + 128 + 1 + 4;
+//   GP, GD          : (input-gradient dX chain only) g_pos (64/sample) and g_view_dir (32/sample), TF layout; a small
+//                     kernel writes the callers' row-major (M, E_p) / (M, E_d) tensors from them
+__host__ __device__ constexpr int64_t gp_plane(int64_t MP) { return MP * (256 * 9 + 128 + 1 + 4); }
+__host__ __device__ constexpr int64_t gd_plane(int64_t MP) { return MP * (256 * 9 + 128 + 1 + 4 + 64); }
+constexpr int DY_FLOATS_PER_SAMPLE = 256 * 9 + 128 + 1 + 4 + 96;
 
 // ---- bf16 inference stream (BASELINE configs[2]: bf16 weights on v_mfma_f32_32x32x16_bf16).
 // [const block (fp32, as above)][sub-step 0]...[sub-step 36]; a sub-step = 32 KiB = what one pipeline step of

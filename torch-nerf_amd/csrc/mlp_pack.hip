@@ -1,5 +1,5 @@
 // Re-tiles the flat NeRF parameter blob (state_dict order) into the stream the fused
-// MLP kernels DMA into LDS: const block + 78 forward chunks + 68 transposed chunks
+// MLP kernels DMA into LDS: const block + 78 forward chunks + 74 transposed chunks
 // (layout: mlp_layout.h).  2.4 MB in, 4.8 MB out; runs once per parameter update.
 #include "common.h"
 #include "mlp_layout.h"
@@ -52,7 +52,11 @@ __device__ float forward_chunk_value(const Params &P, int ci, int n, int kk) {
 
 // chunk of W^T: image row m = INPUT feature, k-group = 32 consecutive OUTPUT features
 __device__ float backward_chunk_value(const Params &P, int ci, int m, int kk) {
-    const int E_POS = P.net.e_pos;
+    const int E_POS = P.net.e_pos, E_DIR = P.net.e_dir;
+    if (ci < BW_FC9T) {   // slot-major: slot kb = direction block x output block kb
+        const int slot = 8 * (ci - BW_DIRT) + (m >> 5), i = m & 31;
+        return (slot < 4 && i < E_DIR) ? P.w(9, 32 * slot + kk, FEAT + i) : 0.0f;
+    }
     if (ci < BW_FC8T) return P.w(9, 32 * (ci - BW_FC9T) + kk, m);
     if (ci < BW_FC7T) return P.w(8, 1 + 32 * (ci - BW_FC8T) + kk, m);
     if (ci < BW_FC5T) {
@@ -60,8 +64,14 @@ __device__ float backward_chunk_value(const Params &P, int ci, int m, int kk) {
         return P.w(l, 32 * cb + kk, m);
     }
     if (ci < BW_FC4T) return P.w(5, 32 * (ci - BW_FC5T) + kk, E_POS + m);
-    const int l = 4 - (ci - BW_FC4T) / 8, cb = (ci - BW_FC4T) % 8;
-    return P.w(l, 32 * cb + kk, m);
+    if (ci < BW_FCINT) {
+        const int l = 4 - (ci - BW_FC4T) / 8, cb = (ci - BW_FC4T) % 8;
+        return P.w(l, 32 * cb + kk, m);
+    }
+    // slot-major: slot 2 kb + fb of fc_in^T / fc_5[:, :E_p]^T
+    const int base = ci < BW_FC5POST ? BW_FCINT : BW_FC5POST;
+    const int slot = 8 * (ci - base) + (m >> 5), k = 32 * (slot & 1) + (m & 31);
+    return k < E_POS ? P.w(ci < BW_FC5POST ? 0 : 5, 32 * (slot >> 1) + kk, k) : 0.0f;
 }
 
 __device__ float const_block_value(const Params &P, int e) {

@@ -33,7 +33,7 @@ enum { IN_ENCODED = 0, IN_SHIPPED = 1, IN_LEVELS = 2 };
 // RAYDIR (render_fused.hip): the direction of this lane's sample is its RAY's, so fc_9's direction contribution was
 // computed once per ray: `fc9_init` points at this lane's ray row of 128 floats (LDS) = fc_9.bias + W9[:, 256:] enc(d),
 // accumulated in the k order of the MFMA chain below -- the accumulators start from it, no direction is encoded, and
-// the direction pair of the stream is neither fetched (Pipe::skip_pair) nor multiplied.  Same bits, 64 MFMAs, one
+// the direction pair of the stream is neither fetched (Pipe::skip_mask) nor multiplied.  Same bits, 64 MFMAs, one
 // acquire and twelve sincos per sample less.
 template <int INPUT, bool SAVE, bool RAYDIR = false, class AfterEncode>
 __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[6], const float *__restrict__ pos,

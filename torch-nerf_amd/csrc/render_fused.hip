@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
     pipe.issue_pos = 0;
     pipe.consumed = 0;
     pipe.n_pairs = FWD_CHUNKS / 2;
-    pipe.skip_pair = FC9_DIR_PAIR;     // the direction's contribution comes per ray (ray_direction_row)
+    pipe.skip_mask = 1ull << FC9_DIR_PAIR;     // the direction's contribution comes per ray (ray_direction_row)
     __syncthreads();
     pipe.issue();
 

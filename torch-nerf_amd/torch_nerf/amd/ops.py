@@ -194,8 +194,10 @@ class ShencFunction(torch.autograd.Function):
     def backward(ctx, g_out):
         (x,) = ctx.saved_tensors
         lib = _lib.load()
-        g_out = _gpu(g_out, "g_out")
-        g_in = torch.empty_like(x)
+        # the forward ran on the contiguous fp32 copy: the reverse kernel must see the same rows (a column slice or a
+        # transposed view has other strides; empty_like would keep them for g_in as well)
+        x, g_out = _gpu(x, "in_signal"), _gpu(g_out, "g_out")
+        g_in = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(lib.nerf_shenc_backward(_ptr(x), _ptr(g_out), x.shape[0], ctx.degree, _ptr(g_in), _stream()),
                        "nerf_shenc_backward")
@@ -349,23 +351,28 @@ def mlp_forward_bf16(packed_bf16: torch.Tensor, pos: torch.Tensor, view_dir: tor
 
 
 def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved, g_sigma, g_rgb,
-                 net: Optional[Net] = None):
-    """Parameter gradients as one flat tensor in state_dict order."""
+                 net: Optional[Net] = None, want_pos: bool = False, want_dir: bool = False):
+    """Parameter gradients as one flat tensor in state_dict order; with want_pos / want_dir -> (g_params, g_pos,
+    g_view_dir): the gradients w.r.t. the ENCODED inputs, (M, pos_dim) / (M, view_dir_dim), None where not asked."""
     lib = _lib.load()
     M = pos.shape[0]
     g_sigma, g_rgb = _gpu(g_sigma, "g_sigma"), _gpu(g_rgb, "g_rgb")
     g_params = torch.empty((lib.nerf_mlp_param_count(_ref(net)),), dtype=torch.float32, device=pos.device)
+    e_p, e_d = (63, 27) if net is None else (net.pos_dim, net.view_dir_dim)
+    g_pos = torch.empty((M, e_p), dtype=torch.float32, device=pos.device) if want_pos else None
+    g_dir = torch.empty((M, e_d), dtype=torch.float32, device=pos.device) if want_dir else None
     ws_bytes = lib.nerf_mlp_backward_workspace_bytes(_ref(net), M)
     ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=pos.device)
     with torch.cuda.device(pos.device):
         end = _timed("mlp_backward", M)
         _lib.check(lib.nerf_mlp_backward(_ref(net), _ptr(packed), _ptr(flat_params), _ptr(pos), _ptr(view_dir), M,
                                          int(bool(encoded)), _ptr(sigma), _ptr(rgb), _ptr(saved),
-                                         _ptr(g_sigma), _ptr(g_rgb), _ptr(g_params), _ptr(ws), _stream()),
+                                         _ptr(g_sigma), _ptr(g_rgb), _ptr(g_params), _ptr(g_pos), _ptr(g_dir),
+                                         _ptr(ws), _stream()),
                    "nerf_mlp_backward")
         if end is not None:
             end.record()
-    return g_params
+    return (g_params, g_pos, g_dir) if (want_pos or want_dir) else g_params
 
 
 def _split_like(g_flat, shapes):
@@ -387,7 +394,9 @@ class NerfMLPFunction(torch.autograd.Function):
     `flat_params` is their concatenation and `packed` its LDS-image stream; `net` an ops.Net (None = shipped).
     `record` selects the training-mode kernel that also writes the activation record for backward; the caller
     decides it from torch.is_grad_enabled() (grad mode is always off inside forward()).
-    Gradients w.r.t. pos / view_dir are not produced here: NeRF.forward routes such calls to NerfLayeredFunction.
+    Differentiable w.r.t. the parameters AND the two inputs, like the reference's autograd graph (nerf.py:102-119):
+    the dX chain returns the gradients of the encoded inputs (three thin GEMMs more, csrc/mlp_backward.hip); for RAW
+    inputs (encoded=False) the reverse of PositionalEncoder.encode (csrc/posenc.hip) is chained behind them.
     """
 
     @staticmethod
@@ -396,10 +405,8 @@ class NerfMLPFunction(torch.autograd.Function):
         ctx.encoded = bool(encoded)
         ctx.net = net
         ctx.shapes = [p.shape for p in params]
-        if pos.requires_grad or view_dir.requires_grad:
-            raise RuntimeError("the fused MLP kernels do not return gradients w.r.t. sample positions / directions; "
-                               "NeRF.forward sends such calls through the layered kernels")
         if need_grad:
+            pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
             sigma, rgb, saved = mlp_forward(packed, pos, view_dir, encoded, save=True, net=net)
             ctx.save_for_backward(pos, view_dir, packed, flat_params, sigma, rgb, saved)
         else:
@@ -413,9 +420,17 @@ class NerfMLPFunction(torch.autograd.Function):
             g_sigma = torch.zeros_like(sigma)
         if g_rgb is None:
             g_rgb = torch.zeros_like(rgb)
-        g_flat = mlp_backward(packed, flat_params, pos, view_dir, ctx.encoded, sigma, rgb, saved,
-                              g_sigma, g_rgb, net=ctx.net)
-        return (None, None, None, None, None, None, None, *_split_like(g_flat, ctx.shapes))
+        want_pos, want_dir = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        out = mlp_backward(packed, flat_params, pos, view_dir, ctx.encoded, sigma, rgb, saved,
+                           g_sigma, g_rgb, net=ctx.net, want_pos=want_pos, want_dir=want_dir)
+        g_flat, g_pos, g_dir = out if (want_pos or want_dir) else (out, None, None)
+        if not ctx.encoded:    # raw points / directions: through the encoders' reverse pass
+            key = (63, 27, 256, 10, 1, 4, 1) if ctx.net is None else ctx.net.key
+            if g_pos is not None:
+                g_pos = posenc_backward(pos, g_pos, key[3], bool(key[4]))
+            if g_dir is not None:
+                g_dir = posenc_backward(view_dir, g_dir, key[5], bool(key[6]))
+        return (g_pos, g_dir, None, None, None, None, None, *_split_like(g_flat, ctx.shapes))
 
 
 # ---- the layered family: any NeRF(pos_dim, view_dir_dim, feat_dim), pre-encoded inputs, input gradients

@@ -11,8 +11,9 @@ optimizer visibility); they are never called.  Two kernel families sit underneat
     signal_encoder/positional_encoding.yaml) and every other coord_encode_level <= 10 / dir_encode_level <= 4 /
     include_input combination the yaml can express (runner_utils.py:584-612): the register-resident kernels of
     csrc/mlp_forward.hip / mlp_backward.hip behind torch_nerf.amd.ops.NerfMLPFunction
-  * any other NeRF(pos_dim, view_dir_dim, feat_dim), and any call that wants gradients w.r.t. its inputs: one MFMA
-    GEMM launch per layer, csrc/mlp_layered.hip behind ops.NerfLayeredFunction
+    (gradients w.r.t. the inputs included: three thin GEMMs more in the dX chain)
+  * any other NeRF(pos_dim, view_dir_dim, feat_dim): one launch per layer, csrc/mlp_layered.hip behind
+    ops.NerfLayeredFunction
 """
 from typing import Tuple
 
@@ -118,9 +119,8 @@ class NeRF(nn.Module):
         params, flat, packed = self._stream()
         record = self._wants_grad(params)
         input_grads = torch.is_grad_enabled() and (pos.requires_grad or view_dir.requires_grad)
-        if self._net.fused and not input_grads:
-            return ops.NerfMLPFunction.apply(pos, view_dir, True, record, packed, flat, self._net, *params)
-        # other widths, or gradients w.r.t. the inputs wanted (the reference's autograd provides them)
+        if self._net.fused:    # (gradients w.r.t. the inputs come out of the same dX chain)
+            return ops.NerfMLPFunction.apply(pos, view_dir, True, record or input_grads, packed, flat, self._net, *params)
         return ops.NerfLayeredFunction.apply(pos, view_dir, record or input_grads, flat, self._net, *params)
 
     def fused_net(self, coord_enc, dir_enc):
@@ -159,15 +159,18 @@ class NeRF(nn.Module):
 
     def forward_fused(self, points: torch.Tensor, view_dirs: torch.Tensor, net=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """points, view_dirs (M,3) RAW: positional encoding happens inside the kernel.  `net` = fused_net(encoders);
-        omitted: the shipped encoders (10 / 4 levels, include_input)."""
+        omitted: PositionalEncoders inferred from the two widths (inferred_net).  Differentiable w.r.t. the parameters
+        and the raw inputs (the reference's autograd reaches both through cube.py:59-72)."""
         params, flat, packed = self._stream()
         if net is None:
             net = self.inferred_net()
             if net is None:
                 raise RuntimeError(f"NeRF({self._pos_dim}, {self._view_dir_dim}, {self._feat_dim}) has no fused query")
-        if self.bf16_inference and net.is_shipped and not self._wants_grad(params):
+        input_grads = torch.is_grad_enabled() and (points.requires_grad or view_dirs.requires_grad)
+        record = self._wants_grad(params) or input_grads
+        if self.bf16_inference and net.is_shipped and not record:
             return ops.mlp_forward_bf16(self._stream_bf16(), points, view_dirs, net)
-        return ops.NerfMLPFunction.apply(points, view_dirs, False, self._wants_grad(params), packed, flat, net, *params)
+        return ops.NerfMLPFunction.apply(points, view_dirs, False, record, packed, flat, net, *params)
 
     pos_dim = property(lambda self: self._pos_dim)
     view_dir_dim = property(lambda self: self._view_dir_dim)

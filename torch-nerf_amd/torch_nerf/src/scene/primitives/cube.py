@@ -40,7 +40,7 @@ class PrimitiveCube(PrimitiveBase):
         num_ray, num_sample = super().query_points(pos, view_dir)
         flat = num_ray * num_sample
         fused = self.fused_net()
-        if fused is not None and not (torch.is_grad_enabled() and (pos.requires_grad or view_dir.requires_grad)):
+        if fused is not None:   # (differentiable w.r.t. pos / view_dir as well)
             sigma, radiance = self._radiance_field.forward_fused(pos.reshape(flat, -1), view_dir.reshape(flat, -1), fused)
         else:
             enc = self._encoders or {}
