@@ -96,8 +96,8 @@ int nerf_posenc(const float *x, int64_t M, int C, int L, int include_input, floa
  * Two kernel families, chosen by nerf_mlp_path(net):
  *   NERF_PATH_FUSED   feat_dim == 256, pos_dim <= 64, view_dir_dim <= 32: the register-resident persistent
  *                     kernels (nerf_mlp_pack / _forward / _backward / _forward_bf16, nerf_render_*)
- *   NERF_PATH_LAYERED anything else: one MFMA GEMM launch per layer with activations in HBM
- *                     (nerf_mlp_layered_*), pre-encoded inputs, also returns the input gradients
+ *   NERF_PATH_LAYERED anything else: the same persistent structure with the activations parked in HBM planes
+ *                     between layers (nerf_mlp_layered_*), pre-encoded inputs, also returns the input gradients
  * `params` is always the flat state_dict blob: fc_in.weight (feat,pos_dim), fc_in.bias, fc_1.weight, ...
  * fc_out.weight (3,feat/2), fc_out.bias = nerf_mlp_param_count(net) floats. */
 typedef struct nerf_net {
@@ -121,7 +121,7 @@ int nerf_mlp_pack(const nerf_net_t *net, const float *params, void *packed, nerf
  * sigma (M,), rgb (M,3).  `saved` = NULL for inference, or nerf_mlp_saved_bytes(net, M)
  * bytes that receive the activation record nerf_mlp_backward needs. */
 int64_t nerf_mlp_saved_bytes(const nerf_net_t *net, int64_t M);
-/* Float offset of element (sample m, feature k) inside a plane of `width` (256 | 128 | 64 | 32) features per
+/* Float offset of element (sample m, feature k) inside a plane of `width` (a multiple of 32) features per
  * sample of the activation record / gradient workspace ("TF" layout, csrc/mlp_layout.h): host-side, for
  * tools and tests; the record's planes are otherwise opaque. */
 int64_t nerf_mlp_plane_offset(int width, int64_t m, int k);
@@ -151,17 +151,23 @@ int nerf_mlp_backward(const nerf_net_t *net, const void *packed, const float *pa
                       void *workspace, nerf_stream_t stream);
 
 /* ---- a10 + a13, NERF_PATH_LAYERED (any pos_dim / view_dir_dim / feat_dim): NeRF.forward on PRE-ENCODED inputs
- * pos (M,pos_dim), view_dir (M,view_dir_dim) as one fp32-MFMA GEMM launch per layer (bias, ReLU, sigmoid and the
- * two torch.cat of nerf.py:108,:116 fused into the GEMMs), activations in `record`:
+ * pos (M,pos_dim), view_dir (M,view_dir_dim).  ONE persistent launch per forward (and one per reverse chain): the
+ * fused family's structure -- 128-sample tiles, weights streamed L2 -> LDS by LDS-DMA from a pre-packed, zero-padded
+ * stream, v_mfma_f32_32x32x2_f32 with the weights as the A operand -- with the activations of a tile parked in HBM
+ * planes between layers (a network of feat_dim 512 does not fit the register file); bias, ReLU / sigmoid and the two
+ * torch.cat of nerf.py:108,:116 are fused; every call packs its streams from `params` first.
  *   record_rows >= M : the whole batch is recorded (what nerf_mlp_layered_backward needs)
  *   record_rows <  M : inference, the batch is walked in chunks of record_rows rows through the same buffer
- * record = nerf_mlp_layered_record_bytes(net, record_rows) bytes.
+ * record = nerf_mlp_layered_record_bytes(net, record_rows) bytes (constant block + forward stream + planes).
  * Backward = autograd's result for nerf.py:102-119: g_params (OVERWRITTEN, layout of `params`) and, when non-NULL,
  * g_pos (M,pos_dim) / g_view_dir (M,view_dir_dim), the gradients w.r.t. the encoded inputs.  No atomics: the
  * sample-axis reductions are split into fixed slices summed in a fixed order (bit-reproducible gradients).
- * workspace: nerf_mlp_layered_workspace_bytes(net, M). */
+ * workspace: nerf_mlp_layered_workspace_bytes(net, M).
+ * nerf_mlp_layered_plane: byte offset + padded width of a record plane (0 pos, 1 dir, 2..9 h0..h7, 10 fc_8[1:], 11 h9),
+ * for tools and tests. */
 int64_t nerf_mlp_layered_record_bytes(const nerf_net_t *net, int64_t rows);
 int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t M);
+int64_t nerf_mlp_layered_plane(const nerf_net_t *net, int64_t rows, int which, int *width);
 int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params, const float *pos, const float *view_dir,
                              int64_t M, float *sigma, float *rgb, void *record, int64_t record_rows,
                              nerf_stream_t stream);

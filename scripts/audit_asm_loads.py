@@ -38,6 +38,8 @@ def audit(path):
     pending = []  # [regset, line_no, younger_asm_reads]
     stores = []   # [data regset, line_no, wait states seen since the store]
     sgpr_writes = []   # [sgpr set, line_no, wait states seen since the VALU write]
+    vloads = []   # [dest regset, line_no, younger VMEM operations]: asm-issued global loads nobody has waited for yet
+    n_vloads = 0
     n_vmem_s = 0
     problems = 0
     total = 0
@@ -54,6 +56,33 @@ def audit(path):
             continue
         op, _, rest = ln.partition(" ")
         toks = [t.strip().rstrip(",") for t in re.split(r"[ ,]+", rest) if t.strip()]
+        # ---- asm-issued global loads (mlp_layered.hip: B operands, ReLU masks): the compiler believes the destination valid
+        # from the moment of issue; nothing may read or write it before a vmcnt wait that covers the load (VMEM returns
+        # in order: vmcnt(N) leaves at most the N youngest operations outstanding)
+        m_vm = re.search(r"vmcnt\((\d+)\)", ln)
+        if op == "s_waitcnt" and m_vm:
+            n_left = int(m_vm.group(1))
+            vloads = [v for v in vloads if v[2] < n_left]
+        elif vloads:
+            is_vmem = op.startswith("global_") or op.startswith("buffer_") or op.startswith("scratch_") or op.startswith("flat_")
+            if not (in_asm and op.startswith("global_load")):
+                touched_v = set()
+                for t in toks:
+                    touched_v |= regs(t)
+                if is_vmem and toks and not op.startswith("global_store") and not op.startswith("buffer_store") and not op.startswith("scratch_store"):
+                    pass
+                for v in vloads:
+                    if touched_v & v[0]:
+                        problems += 1
+                        print(f"{path}:{no}: `{ln[:70]}` touches v{sorted(touched_v & v[0])[:4]} of the asm-issued global load at "
+                              f"line {v[1]} before a covering s_waitcnt vmcnt")
+                        v[0] -= touched_v
+            if is_vmem:
+                for v in vloads:
+                    v[2] += 1
+        if in_asm and op in ("global_load_dwordx4", "global_load_dword") and toks and not ln.rstrip().endswith("lds"):
+            vloads.append([regs(toks[0]), no, 0])
+            n_vloads += 1
         # ---- wide-store data hazard: 2 wait states before a VALU write of the stored registers
         if stores:
             if op.startswith("v_") and toks:
@@ -114,7 +143,8 @@ def audit(path):
             if touched & p[0]:
                 problems += 1
                 print(f"{path}:{no}: `{ln[:70]}` touches v{sorted(touched & p[0])} of the un-waited read at line {p[1]}")
-    print(f"{path}: {n_stores} asm-issued wide stores, {n_vmem_s} asm-issued VMEM instructions with SGPR operands checked")
+    print(f"{path}: {n_stores} asm-issued wide stores, {n_vmem_s} asm-issued VMEM instructions with SGPR operands, "
+          f"{n_vloads} asm-issued global loads checked")
     print(f"{path}: {total} hand-issued LDS reads, {problems} problems")
     return problems
 

@@ -51,15 +51,31 @@ def fused_masks(saved, sigma, M):
     return out
 
 
-def layered_masks(rec, sigma, M, F):
-    """The same decisions from the layered family's record (row-major planes h0..h7 (M,F), y8 (M,F+1), h9 (M,F/2))."""
-    r = rec.cpu().numpy()
-    H = F // 2
+def layered_plane(rec, net, M, which):
+    """Plane `which` of the layered family's record (nerf_mlp_layered_plane: 0 pos, 1 dir, 2..9 h0..h7, 10 fc_8[1:],
+    11 h9) as an (M, width) array: decoded from the tile-fragment layout with nerf_mlp_plane_offset."""
+    import ctypes
+    from torch_nerf.amd import _lib
+    lib = _lib.load()
+    width = ctypes.c_int(0)
+    off = lib.nerf_mlp_layered_plane(net.ref, M, which, ctypes.byref(width))
+    assert off >= 0 and off % 4 == 0
+    W = width.value
+    MP = (M + 127) // 128 * 128
+    raw = rec.cpu().numpy().view(np.float32)[off // 4: off // 4 + MP * W]
+    # tf_offset(width, m, k) is linear in the tile index: build the index map of one 32-sample tile once
+    tile = np.array([[lib.nerf_mlp_plane_offset(W, m, k) for k in range(W)] for m in range(32)], np.int64)
+    idx = (np.arange(MP // 32, dtype=np.int64)[:, None, None] * 32 * W + tile[None]).reshape(MP, W)
+    return raw[idx][:M]
+
+
+def layered_masks(rec, sigma, M, net):
+    """The same decisions from the layered family's record, in the oracle's layout (M, 8 F + F/2 + 1)."""
+    F, H = net.feat_dim, net.feat_dim // 2
     out = np.zeros((M, 8 * F + H + 1), np.uint8)
     for l in range(8):
-        out[:, l * F:(l + 1) * F] = r[M * F * l: M * F * (l + 1)].reshape(M, F) > 0
-    h9 = r[M * F * 8 + M * (F + 1): M * F * 8 + M * (F + 1) + M * H].reshape(M, H)
-    out[:, 8 * F:8 * F + H] = h9 > 0
+        out[:, l * F:(l + 1) * F] = layered_plane(rec, net, M, 2 + l)[:, :F] > 0
+    out[:, 8 * F:8 * F + H] = layered_plane(rec, net, M, 11)[:, :H] > 0
     out[:, -1] = sigma.cpu().numpy() > 0
     return out
 

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_header():
     assert lib.nerf_amd_abi_version() == 3
     assert lib.nerf_mlp_param_count(None) == 595844
     # sizes only -- no compute without a GPU
-    assert lib.nerf_mlp_packed_bytes(None) == 13312 + (78 + 68) * 32768
+    assert lib.nerf_mlp_packed_bytes(None) == 13312 + (78 + 74) * 32768   # 68 transposed chunks + 3 input-gradient pairs
     assert lib.nerf_mlp_saved_bytes(None, 128) == 128 * (2528 * 4 + 9 * 32)
     assert lib.nerf_mlp_saved_bytes(None, 129) == 256 * (2528 * 4 + 9 * 32)  # rows padded to 128
 
@@ -47,8 +47,15 @@ def test_network_descriptions_choose_the_kernel_family():
         n = net(e_p, e_d, feat, lp, inc, ld, inc)
         assert lib.nerf_mlp_path(n) == path, (lp, ld, inc, feat)
         assert lib.nerf_mlp_param_count(n) == synth.param_count(e_p, e_d, feat)
-        assert (lib.nerf_mlp_packed_bytes(n) > 0) == (path == 0)      # the layered family streams `params` as they are
-        assert lib.nerf_mlp_layered_record_bytes(n, 10) == 40 * (8 * feat + feat + 1 + feat // 2)
+        assert (lib.nerf_mlp_packed_bytes(n) > 0) == (path == 0)      # the layered family packs inside its calls
+        # record = constant block + forward stream + 128 padded rows of planes (two inputs, h0..h7, fc_8[1:], h9)
+        r32 = lambda v: (v + 31) // 32 * 32
+        planes = 128 * 4 * (r32(e_p) + r32(e_d) + 9 * r32(feat) + r32(feat // 2))
+        assert lib.nerf_mlp_layered_record_bytes(n, 10) > planes
+        import ctypes as _ct
+        w = _ct.c_int(0)
+        assert lib.nerf_mlp_layered_plane(n, 10, 11, _ct.byref(w)) == lib.nerf_mlp_layered_record_bytes(n, 10) - 128 * 4 * r32(feat // 2)
+        assert w.value == r32(feat // 2)
         assert lib.nerf_mlp_layered_workspace_bytes(n, 1000) > 0
     # encoders the kernels do not know (levels < 0): any widths, pre-encoded entries only
     assert lib.nerf_mlp_path(net(16, 16, 256, -1, 0, -1, 0)) == 0          # e.g. SHEncoder(3, 4) on both inputs
@@ -106,7 +113,7 @@ def test_entry_points_refuse_what_they_cannot_serve_before_touching_the_gpu():
     p = ctypes.cast(ctypes.pointer(one), ctypes.c_void_p)                          # any non-null address: never dereferenced
     assert lib.nerf_mlp_pack(f128, p, p, None) == UNSUPPORTED and b"nerf_mlp_layered" in lib.nerf_amd_last_error()
     assert lib.nerf_mlp_forward(f128, p, p, p, 4, 1, p, p, None, None) == UNSUPPORTED
-    assert lib.nerf_mlp_backward(f128, p, p, p, p, 4, 1, p, p, p, p, p, p, p, None) == UNSUPPORTED
+    assert lib.nerf_mlp_backward(f128, p, p, p, p, 4, 1, p, p, p, p, p, p, None, None, p, None) == UNSUPPORTED
     assert lib.nerf_render_pass(f128, p, p, p, 4, 64, 0, p, 0.1, None, p, None, None, p, p, None, None, None, None) == UNSUPPORTED
     assert lib.nerf_mlp_packed_bytes(f128) == -1 and lib.nerf_mlp_saved_bytes(f128, 10) == -1
     sh = net(16, 16, 256, -1, 0, -1, 0)                                            # fused widths, encoders unknown

@@ -153,7 +153,7 @@ def test_full_tensor_vs_oracle(oracle, golden, tag, M):
     sigma, rgb, rec = ops.mlp_layered_forward(fp, dev(pe), dev(de), spec, record=True)
     np.testing.assert_allclose(sigma.cpu().numpy(), want_s, rtol=0, atol=1e-5)
     np.testing.assert_allclose(rgb.cpu().numpy(), want_c, rtol=0, atol=1e-5)
-    masks = layered_masks(rec, sigma, M, feat)
+    masks = layered_masks(rec, sigma, M, spec)
     assert (masks != own).mean() < 1e-5, f"{(masks != own).sum()} ReLU decisions differ from the oracle's"
     want_g, want_gp, want_gd, _ = oracle.mlp_backward_ex(flat, pe, de, gs, gc, F=feat, force_masks=masks)
     got, g_pos, g_dir = ops.mlp_layered_backward(fp, dev(pe), dev(de), spec, sigma, rgb, rec, dev(gs), dev(gc),

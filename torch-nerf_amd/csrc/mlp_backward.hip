@@ -276,8 +276,10 @@ constexpr int DW_LDS_BYTES = 131072 + 1024;  // 2 stages of 64 KiB (wide X) or 3
 enum { FLAG_BIAS = 1, FLAG_DENSITY = 2, FLAG_FCOUT = 4 };   // side jobs of the fc_8 / fc_9 items (dw_body)
 
 struct GemmDesc {
-    int64_t a_off;        // dY plane, float offset into the dy workspace
-    int64_t x_off;        // X plane, float offset into the saved record
+    const char *a_src;    // dY plane window: tile t at a_src + t * a_stride, 32 x a_width floats contiguous
+    const char *x_src;    // X plane window, likewise
+    int64_t a_stride, x_stride;   // bytes between 32-sample tiles (= 128 x the plane's width; a window narrower than
+                                  // its plane is a run of whole 4-KiB feature blocks inside the tile)
     int64_t partial_off;  // float offset of slice 0 in the partial buffer
     int64_t w_off;        // destination: weight tensor offset in the flat gradient
     int64_t b_off;        // destination: bias offset (row0 already applied by the reducer)
@@ -290,12 +292,18 @@ struct GemmDesc {
     int in_features;      // row stride of the destination weight tensor
     int col0, valid_cols; // destination column block
     int row0;             // destination row offset (1 for fc_8: row 0 is the density row)
+    int valid_rows;       // rows of the window that exist in the destination (a_width for the fused family)
 };
 struct GemmTable {
     GemmDesc g[MAX_GEMMS];
     int n;
     int64_t work_total;           // sum over items of tiles * cost
     int64_t off_b8, off_wout, off_bout;   // flat-gradient offsets of fc_8.bias, fc_out.weight, fc_out.bias
+};
+// the same for the layered family, whose item lists do not fit a kernel argument: header + items in device memory
+struct GemmList {
+    int n;
+    int64_t work_total;
 };
 
 __device__ __forceinline__ int64_t slice_stride(const GemmDesc &g) {
@@ -315,10 +323,12 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned lds_addr, int imm_offset
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 3 || N == 5 || N == 10, "add the immediate below");
+    static_assert(N == 0 || N == 3 || N == 5 || N == 6 || N == 9 || N == 10, "add the immediate below");
     if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
     if (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    if (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    if (N == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
     if (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
 }
 
@@ -360,8 +370,9 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
     const int frag_base = (i >> 3) * 256 + 4 * ((2 * h + ((i >> 2) & 1)) ^ (2 * ((i >> 3) & 1))) + (i & 3);
     const int frag_swing = 16 * (i >> 4);
     const bool want_bias = (g.flags & FLAG_BIAS) != 0;   // tiles [t0, t1) of the item; an empty range writes a zero partial
-    const char *a_src = reinterpret_cast<const char *>(dy + g.a_off);      // wave-uniform; the lane offset rides
-    const char *x_src = reinterpret_cast<const char *>(saved + g.x_off);   // in the DMA instruction's vector operand
+    const char *a_src = g.a_src;   // wave-uniform; the lane offset rides in the DMA instruction's vector operand
+    const char *x_src = g.x_src;
+    const int64_t a_stride = g.a_stride, x_stride = g.x_stride;
     const char *h9_src = reinterpret_cast<const char *>(saved + pl_h9(MP));
     const unsigned lane_off = (unsigned)lane * 16u;
     float *out = partial + g.partial_off + slice * slice_stride(g);
@@ -408,10 +419,10 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
     auto issue_piece = [&](int64_t t, int buf, int j) {
         const unsigned ad = lds_base + buf * STAGE_BYTES;
         if (j < A_PIECES) {
-            lds_dma_16s(a_src + t * A_BYTES + (wave + 4 * j) * 1024, lane_off, ad + (wave + 4 * j) * 1024);
+            lds_dma_16s(a_src + t * a_stride + (wave + 4 * j) * 1024, lane_off, ad + (wave + 4 * j) * 1024);
         } else if (j < A_PIECES + X_PIECES) {
             const int jx = j - A_PIECES;
-            lds_dma_16s(x_src + t * X_BYTES + (wave + 4 * jx) * 1024, lane_off, ad + A_BYTES + (wave + 4 * jx) * 1024);
+            lds_dma_16s(x_src + t * x_stride + (wave + 4 * jx) * 1024, lane_off, ad + A_BYTES + (wave + 4 * jx) * 1024);
         } else {
             const int jh = j - A_PIECES - X_PIECES;
             lds_dma_16s(h9_src + t * H9_BYTES + (wave + 4 * jh) * 1024, lane_off, ad + A_BYTES + X_BYTES + (wave + 4 * jh) * 1024);
@@ -511,6 +522,9 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
 #undef DW_FETCH
         buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     }
+    // the side jobs' last hand-issued prefetch is never consumed: its destination registers are dead from here on and
+    // hipcc re-uses them at once -- the load has had a whole tile to land, but nothing SAYS so (scripts/audit_asm_loads.py)
+    if (DENSITY || FCOUT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // partial tile of this slice: row-major [AW][XW], then bias[AW].  Stores in saddr form -- scalar row base (SALU),
     // ONE lane register (4 h XW + i) * 4, the feature block in the immediate -- straight out of the accumulator
     // registers.  (hipcc's own version of this loop precomputes 256 64-bit vector addresses, hoists them out of the
@@ -551,12 +565,9 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
     }
 }
 
-__global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, const float *__restrict__ saved,
-                                                             const float *__restrict__ dy,
-                                                             float *__restrict__ partial, int64_t M,
-                                                             unsigned long long *__restrict__ block_clocks) {
-    const unsigned long long clk0 = block_clocks ? wall_clock64() : 0;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+__device__ __forceinline__ void dw_main(const GemmDesc *items, int n_items, int64_t work_total,
+                                        const float *__restrict__ saved, const float *__restrict__ dy,
+                                        float *__restrict__ partial, int64_t M, char *lds) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -568,10 +579,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, con
     // of equal slices: 251 of 256 CUs busy and 5 % between the first and the last workgroup to finish).
     const int64_t tiles = MP / 32;
     const int64_t B = gridDim.x, b = blockIdx.x;
-    const int64_t lo = table.work_total * b / B, hi = table.work_total * (b + 1) / B;
+    const int64_t lo = work_total * b / B, hi = work_total * (b + 1) / B;
     bool first = true;
-    for (int k = 0; k < table.n; ++k) {
-        const GemmDesc &g = table.g[k];
+    for (int k = 0; k < n_items; ++k) {
+        const GemmDesc &g = items[k];
         const int slice = (int)b - g.first_block;
         if (slice < 0 || slice >= g.num_slices) continue;
         auto tile_at = [&](int64_t unit) {   // first tile of the item that starts at or after `unit`
@@ -598,21 +609,51 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, con
         } else if (g.a_width == 256 && g.x_width == 256) dw_body<2, 8>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 256 && g.x_width == 64) dw_body<2, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 128 && g.x_width == 256) dw_body<1, 8>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
-        else dw_body<1, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_width == 128 && g.x_width == 32) dw_body<1, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+#ifndef NERF_DW_FUSED_SHAPES_ONLY   // the other window shapes of the layered family
+        else if (g.a_width == 256 && g.x_width == 128) dw_body<2, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_width == 256 && g.x_width == 32) dw_body<2, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_width == 128 && g.x_width == 128) dw_body<1, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else dw_body<1, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (block_clocks && tid == 0) block_clocks[blockIdx.x] = wall_clock64() - clk0;  // 100 MHz ticks
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, const float *__restrict__ saved,
+                                                             const float *__restrict__ dy,
+                                                             float *__restrict__ partial, int64_t M,
+                                                             unsigned long long *__restrict__ block_clocks) {
+    const unsigned long long clk0 = block_clocks ? wall_clock64() : 0;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    dw_main(table.g, table.n, table.work_total, saved, dy, partial, M, lds);
+    if (block_clocks && threadIdx.x == 0) block_clocks[blockIdx.x] = wall_clock64() - clk0;  // 100 MHz ticks
+}
+
+// the layered family's item list lives in device memory (header + items)
+__global__ __launch_bounds__(256, 1) void mlp_bwd_dw_list_kernel(const GemmList *__restrict__ list,
+                                                                  float *__restrict__ partial, int64_t M) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const GemmDesc *items = reinterpret_cast<const GemmDesc *>(list + 1);
+    dw_main(items, list->n, list->work_total, nullptr, nullptr, partial, M, lds);
 }
 
 // ------------------------------------------------------------------------------------------
 // stage 3: reduce partial tiles into the flat gradient (state_dict layout), fixed order
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void reduce_item(const GemmDesc &g, const float *__restrict__ partial, int64_t off_wout,
+                                            float *__restrict__ g_params);
+
+__global__ void mlp_bwd_reduce_list_kernel(const GemmList *__restrict__ list, const float *__restrict__ partial,
+                                           float *__restrict__ g_params) {
+    const GemmDesc *items = reinterpret_cast<const GemmDesc *>(list + 1);
+    if ((int)blockIdx.y < list->n) reduce_item(items[blockIdx.y], partial, 0, g_params);
+}
+
 __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__ partial,
                                       const float *__restrict__ bias_partial, int bias_partials,
                                       float *__restrict__ g_params) {
     const int gi = blockIdx.y;
-    const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
     if (gi >= table.n) {  // the four scalar-output bias gradients: per-wavefront partials of the dX chain, fixed order
         __shared__ float part[64][4];
         if (blockIdx.x != 0) return;
@@ -628,11 +669,17 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
         }
         return;
     }
-    const GemmDesc &g = table.g[gi];
+    reduce_item(table.g[gi], partial, table.off_wout, g_params);
+}
+
+__device__ __forceinline__ void reduce_item(const GemmDesc &g, const float *__restrict__ partial, int64_t off_wout,
+                                            float *__restrict__ g_params) {
+    const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
     const float *base = partial + g.partial_off;
     const int64_t stride = slice_stride(g);
-    const int64_t tile = (int64_t)g.a_width * g.valid_cols;
-    const int64_t with_bias = tile + ((g.flags & FLAG_BIAS) ? g.a_width : 0);
+    const int64_t tile = (int64_t)g.valid_rows * g.valid_cols;
+    const int64_t with_bias = tile + ((g.flags & FLAG_BIAS) ? g.valid_rows : 0);
     const int64_t total = with_bias + ((g.flags & FLAG_DENSITY) ? FEAT : (g.flags & FLAG_FCOUT) ? 3 * HALF : 0);
     for (int64_t e = e0; e < total; e += step) {
         int64_t src, dst;
@@ -647,7 +694,7 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
         } else {   // side-job rows: density row of fc_8 = weight[0, :]; fc_out.weight (3 x 128, contiguous)
             const int k = (int)(e - with_bias);
             src = (int64_t)g.a_width * g.x_width + 256 + k;
-            dst = (g.flags & FLAG_DENSITY) ? g.w_off + k : table.off_wout + k;
+            dst = (g.flags & FLAG_DENSITY) ? g.w_off + k : off_wout + k;
         }
         // slices are added in index order (bit-reproducible); the loads of four slices are issued together so that the
         // walk is not one dependent HBM round trip per slice
@@ -672,7 +719,7 @@ struct Plan {
     int64_t partial_floats;
 };
 
-Plan make_plan(const Net &net, int64_t M, int cus) {
+Plan make_plan(const Net &net, int64_t M, int cus, const float *saved, const float *dy) {
     const int E_POS = net.e_pos, E_DIR = net.e_dir;
     const int64_t MP = padded_rows(M);
     const int64_t tiles = MP / 32;
@@ -682,7 +729,9 @@ Plan make_plan(const Net &net, int64_t M, int cus) {
     auto add = [&](int layer, int64_t a_off, int a_width, int64_t x_off, int x_width, int col0, int valid_cols,
                    int row0, int flags) {
         GemmDesc &g = T.g[n++];
-        g.a_off = a_off; g.x_off = x_off; g.a_width = a_width; g.x_width = x_width;
+        g.a_src = reinterpret_cast<const char *>(dy + a_off); g.x_src = reinterpret_cast<const char *>(saved + x_off);
+        g.a_stride = 128 * (int64_t)a_width; g.x_stride = 128 * (int64_t)x_width; g.valid_rows = a_width;
+        g.a_width = a_width; g.x_width = x_width;
         g.flags = flags; g.in_features = net.layer_in(layer); g.col0 = col0; g.valid_cols = valid_cols; g.row0 = row0;
         g.w_off = net.w_offset(layer); g.b_off = net.b_offset(layer);
     };
@@ -735,6 +784,94 @@ inline int64_t align256f(int64_t floats) { return (floats + 63) & ~(int64_t)63; 
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// the dW GEMMs over arbitrary tile-fragment planes (mlp_layered.hip): windows of <= 256 x 256
+// ------------------------------------------------------------------------------------------
+namespace nerf {
+struct DwItem {   // (mirrors the declaration in mlp_layered.hip)
+    const float *a_plane; int a_width, a_fb0, a_blocks;
+    const float *x_plane; int x_width, x_fb0, x_blocks;
+    float *w_dst; int ld;
+    int rows_valid, cols_valid;
+    float *b_dst;
+};
+
+int64_t dw_items_scratch_bytes(int n_items) {
+    const int64_t list = (16 + (int64_t)n_items * (int64_t)sizeof(GemmDesc) + 255) & ~(int64_t)255;
+    return list + 4 * (int64_t)(512 + n_items) * (256 * 256 + SLICE_EXTRA);
+}
+
+int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int64_t scratch_bytes, hipStream_t s) {
+    const int n = (int)items.size();
+    if (n == 0 || M <= 0) return NERF_OK;
+    static nerf::DeviceMask configured{0};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_dw_list_kernel), DW_LDS_BYTES, configured,
+                                          "nerf_mlp_layered_backward: LDS attribute (dW)"))
+        return rc;
+    const int cus = nerf::device_cus();
+    const int64_t MP = mlp::padded_rows(M), tiles = MP / 32;
+    // destination offsets are taken from the lowest destination pointer of the list
+    float *base = items[0].w_dst;
+    for (const DwItem &it : items) {
+        if (it.w_dst < base) base = it.w_dst;
+        if (it.b_dst && it.b_dst < base) base = it.b_dst;
+    }
+    std::vector<char> host(16 + (size_t)n * sizeof(GemmDesc));
+    GemmList *hdr = reinterpret_cast<GemmList *>(host.data());
+    GemmDesc *G = reinterpret_cast<GemmDesc *>(host.data() + sizeof(GemmList));
+    static_assert(sizeof(GemmList) == 16, "header size");
+    int64_t units = 0;
+    for (int k = 0; k < n; ++k) {
+        const DwItem &it = items[k];
+        GemmDesc &g = G[k];
+        const int NA = it.a_blocks > 4 ? 2 : 1;
+        const int KB = it.x_blocks > 4 ? 8 : it.x_blocks > 2 ? 4 : it.x_blocks > 1 ? 2 : 1;
+        g.a_width = 128 * NA; g.x_width = 32 * KB;
+        // (a window wider than what is left of its plane runs on into the next tile's first blocks: finite values in
+        // rows / columns the reduction never reads)
+        g.a_src = reinterpret_cast<const char *>(it.a_plane + (int64_t)it.a_fb0 * 1024);
+        g.x_src = reinterpret_cast<const char *>(it.x_plane + (int64_t)it.x_fb0 * 1024);
+        g.a_stride = 128 * (int64_t)it.a_width; g.x_stride = 128 * (int64_t)it.x_width;
+        g.flags = it.b_dst ? FLAG_BIAS : 0;
+        g.in_features = it.ld; g.col0 = 0; g.row0 = 0;
+        g.valid_cols = it.cols_valid; g.valid_rows = it.rows_valid;
+        g.w_off = it.w_dst - base; g.b_off = it.b_dst ? it.b_dst - base : 0;
+        // relative tile times by shape (measured for the fused family's four shapes, mlp_backward.hip:make_plan)
+        const int nk = NA * KB;
+        g.cost = nk == 16 ? 7350 : (NA == 1 && KB == 8) ? 3770 : (NA == 2 && KB == 2) ? 2010 : nk == 1 ? 935 : 450 * nk + 150;
+        g.unit_off = units;
+        units += tiles * g.cost;
+    }
+    hdr->n = n; hdr->work_total = units;
+    const int64_t B = tiles * n < cus ? tiles * n : cus;
+    auto owner = [&](int64_t unit) {
+        int64_t b = unit * B / units;
+        while (b + 1 < B && units * (b + 1) / B <= unit) ++b;
+        while (b > 0 && units * b / B > unit) --b;
+        return (int)b;
+    };
+    int64_t off = 0;
+    for (int k = 0; k < n; ++k) {
+        const int fb = owner(G[k].unit_off), lb = owner(G[k].unit_off + (tiles - 1) * G[k].cost);
+        G[k].first_block = fb; G[k].num_slices = lb - fb + 1; G[k].partial_off = off;
+        off += (int64_t)G[k].num_slices * ((int64_t)G[k].a_width * G[k].x_width + SLICE_EXTRA);
+    }
+    const int64_t list_bytes = ((int64_t)host.size() + 255) & ~(int64_t)255;
+    if (list_bytes + 4 * off > scratch_bytes)
+        return nerf::fail(NERF_ERR_ARG, "nerf_mlp_layered_backward: workspace too small for the dW partial tiles");
+    // pageable source: the runtime stages the bytes before it returns, so `host` may go out of scope
+    if (hipMemcpyAsync(scratch, host.data(), host.size(), hipMemcpyHostToDevice, s) != hipSuccess)
+        return nerf::check_launch("nerf_mlp_layered_backward: item list upload");
+    const GemmList *list = static_cast<const GemmList *>(scratch);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(scratch) + list_bytes);
+    hipLaunchKernelGGL(mlp_bwd_dw_list_kernel, dim3((unsigned)B), dim3(256), DW_LDS_BYTES, s, list, partial, M);
+    if (int rc = nerf::check_launch("nerf_mlp_layered_backward: dW")) return rc;
+    hipLaunchKernelGGL(mlp_bwd_reduce_list_kernel, dim3(64, n), dim3(256), 0, s, list,
+                       static_cast<const float *>(partial), base);
+    return nerf::check_launch("nerf_mlp_layered_backward: reduce");
+}
+}  // namespace nerf
+
 NERF_API int64_t nerf_mlp_backward_workspace_bytes(const nerf_net_t *net, int64_t M) {
     mlp::Net n;
     if (nerf::fused_net(net, n, "nerf_mlp_backward_workspace_bytes") != NERF_OK) return -1;
@@ -776,9 +913,9 @@ NERF_API int nerf_mlp_backward(const nerf_net_t *net_abi, const void *packed, co
     const int64_t MP = mlp::padded_rows(M);
     float *dy = static_cast<float *>(workspace);
     float *partial = dy + align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE);
-    const Plan plan = make_plan(net, M, cus);
-    float *bias_partial = partial + plan.partial_floats;
     const float *sv = static_cast<const float *>(saved);
+    const Plan plan = make_plan(net, M, cus, sv, dy);
+    float *bias_partial = partial + plan.partial_floats;
 
     const int64_t ntiles = MP / mlp::TILE_SAMPLES;
     const unsigned dx_grid = (unsigned)(ntiles < cus ? ntiles : (cus < 1024 ? cus : 1024));

@@ -210,7 +210,7 @@ __device__ __forceinline__ void lds_fragments_ready() {
 template <int NFB, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, const char *chunk,
                                           const int (&offq)[4], const Pipe *pipe = nullptr) {
-    constexpr int GROUPS = 4 * NFB, EVERY = N_PIECES > 0 ? GROUPS / N_PIECES : 1;
+    constexpr int GROUPS = 4 * NFB, EVERY = GROUPS / (N_PIECES > 0 ? N_PIECES : GROUPS);
     // A fragments are fetched one (q, fb) group ahead of the MFMAs that consume them, into two
     // alternating buffers: a ds_read_b128 issued behind a group's last MFMA returns ~80 cycles
     // later than the matrix pipe frees up, which with a single buffer costs ~14 idle cycles per group.
@@ -246,7 +246,7 @@ template <int NFB, int NKB, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = 
 __device__ __forceinline__ void mma_slots(f32x16 *acc, const f32x16 *b, const char *chunk, const int (&offq)[4],
                                           const Pipe *pipe = nullptr) {
     static_assert(NFB * NKB <= 8, "a chunk holds eight slots");
-    constexpr int GROUPS = 4 * NFB * NKB, EVERY = N_PIECES > 0 ? GROUPS / N_PIECES : 1;
+    constexpr int GROUPS = 4 * NFB * NKB, EVERY = GROUPS / (N_PIECES > 0 ? N_PIECES : GROUPS);
     const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)chunk;
     unsigned addr[4];
 #pragma unroll

@@ -125,7 +125,7 @@ int launch_forward(const Net &net, const void *packed, const float *pos, const f
 }  // namespace
 
 NERF_API int64_t nerf_mlp_plane_offset(int width, int64_t m, int k) {
-    if ((width != 256 && width != 128 && width != 64 && width != 32) || m < 0 || k < 0 || k >= width) return -1;
+    if (width <= 0 || width % 32 || m < 0 || k < 0 || k >= width) return -1;
     return mlp::tf_offset(width, m, k);
 }
 

@@ -1,330 +1,681 @@
-// a10 + a13 for ANY NeRF(pos_dim, view_dir_dim, feat_dim) (R/network/nerf.py:24-63): the layer-by-layer family.
+// a10 + a13 for ANY NeRF(pos_dim, view_dir_dim, feat_dim) (R/network/nerf.py:24-63): the "layered" family.
 //
-// The register-resident kernels (mlp_forward.hip, mlp_backward.hip) are built around feat_dim = 256 and inputs of at
-// most 64 / 32 encoded features.  Every other network the reference's constructor accepts -- other feat_dim, wider
-// encodings (coord_encode_level > 10), any encoder output width -- runs here: one fp32-MFMA GEMM launch per layer with
-// the activations in HBM, the way the reference's eager path does it (nerf.py:102-119), minus its extra passes:
-// bias, ReLU / sigmoid, the two torch.cat (:108, :116) and the ReLU masks of the backward are fused into the GEMMs.
-// Correct first, reasonably fast second: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), 64..128 x 64..128 x 16 LDS
-// tiles, register prefetch of the next k-tile; no attempt at the 0.9-of-peak of the fused family.
+// The register-resident kernels (mlp_forward.hip, mlp_backward.hip) carry a sample's 256 activations through the
+// whole network in registers.  A wider network (feat_dim 512: 512 inputs + 512 outputs per layer) does not fit, so
+// this family PARKS the activations of a tile in HBM planes between layers -- and keeps everything else of the
+// fused design:
+//  * one persistent launch per forward (and one per reverse chain); workgroup = 4 wavefronts x 32 samples; a workgroup
+//    takes a 128-sample tile through ALL layers itself, so no workgroup ever waits for another one: a lane reads back,
+//    one layer later, exactly the 16-byte groups it stored (the tile-fragment plane layout of mlp_layout.h: the D
+//    fragment a lane holds IS the B fragment it needs next) -- L2-hot, coalesced 1-KiB loads / stores
+//  * transposed GEMM Y^T = W X^T on v_mfma_f32_32x32x2_f32, weights = A operand streamed L2 -> LDS ring by LDS-DMA
+//    (mlp_device.h: Pipe), pre-packed once per call into zero-padded slot-major 64-KiB pairs: NO bounds checks, NO
+//    branches and no address arithmetic in the k-loop (the first version of this file: per-element bounds-checked
+//    scalar staging loads, 64 x 64 x 16 tiles, one launch per layer: 0.18-0.46 of the MFMA peak)
+//  * a layer is cut into PASSES of <= 8 output blocks (256 features = 128 accumulator registers); the B operand of a
+//    pass streams through registers one pair (64 KiB of weights) ahead, as asm-issued loads the pair's own
+//    s_waitcnt vmcnt(0) covers
+//  * bias = initial accumulator, ReLU / the ReLU mask of the reverse chain in the epilogue, both torch.cat
+//    (nerf.py:108, :116) = a pass with two source planes; the density row and fc_out (+ sigmoid) are vector side jobs
+//  * dW = the dW GEMM kernel of mlp_backward.hip over the same planes (nerf::run_dw_items), thin rows by a vector kernel
+// Padded widths (multiples of 32) carry exact zeros, so they add nothing to any sum.
 //
-// One kernel, three roles (all "C[i,j] = sum_k A(i,k) B(k,j)" with run-time strides):
-//   forward   Y[m,n]  = act(sum_k X[m,k] W[n,k] + b[n])     k runs over ONE or TWO concatenated inputs (torch.cat)
-//   dX        G'[m,k] = (sum_n G[m,n] W[n,k]) . [H[m,k] > 0]
-//   dW, db    dW[n,k] = sum_m G[m,n] X[m,k], db[n] = sum_m G[m,n]: the sample axis is the reduction; it is cut into a
-//             FIXED number of slices (grid.z) whose partial tiles a second kernel adds in a fixed order -- no atomics,
-//             bit-reproducible gradients.  db rides along as one extra all-ones column of X.
-// Backward also returns autograd's gradients w.r.t. the (encoded) inputs `pos` / `view_dir` when asked.
-#include "common.h"
+// The pass programs are pure functions of the widths (fwd_pass / dx_pass, __host__ __device__): the kernels
+// evaluate them on the scalar unit at every pass boundary, the pack kernel evaluates them per pair.
+#include <vector>
+
+#include "mlp_device.h"
 #include "net.h"
+
+namespace nerf {
+// mlp_backward.hip: the dW GEMMs of the fused family over arbitrary TF planes
+struct DwItem {
+    const float *a_plane; int a_width, a_fb0, a_blocks;   // dY plane (floats/sample), first block, blocks wanted (<= 8)
+    const float *x_plane; int x_width, x_fb0, x_blocks;   // X plane, window of <= 8 blocks
+    float *w_dst; int ld;                                 // dW[(a_fb0*32 + n) * ld + x_fb0*32 + k] destination (row n, col k)
+    int rows_valid, cols_valid;                           // of the window
+    float *b_dst;                                         // bias gradient for the window's rows, or null
+};
+int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int64_t scratch_bytes, hipStream_t s);
+int64_t dw_items_scratch_bytes(int n_items);
+}  // namespace nerf
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace mlp;
 
-constexpr int TI = 64, TJ = 64, TK = 16;   // base tile (x WI, x WJ); LDS rows are padded by one float
+constexpr int ROUND32(int x) { return (x + 31) & ~31; }
 
-struct GemmArgs {
-    // A operand, element (i, k): segment 1 for k < K1, segment 2 for K1 <= k < K1 + K2 (torch.cat along k)
-    const float *A1; int64_t a1_si, a1_sk; int64_t K1;
-    const float *A2; int64_t a2_si, a2_sk; int64_t K2;
-    // B operand, element (k, j) at B[k * b_sk + j * b_sj]; column j == ones_col reads as 1.0 (bias-gradient column)
-    const float *B; int64_t b_sk, b_sj;
-    int I, J;                 // output extent (J counts the ones column if there is one)
-    int ones_col;             // -1: none
-    int a_kfast, b_kfast;     // which index is contiguous in memory (thread -> element mapping of the tile loads)
-    // split of the reduction over grid.z: slice z covers k in [z * k_chunk, (z+1) * k_chunk); writes C + z * c_slice
-    int64_t k_chunk, c_slice;
-    // epilogue
-    float *C; int64_t c_si;   // element (i, j) at C[i * c_si + j]
-    const float *bias;        // per j, or null
-    int act;                  // 0 none, 1 relu, 2 sigmoid
-    const float *mask; int64_t mask_si;   // multiply by (mask[i * mask_si + j] > 0), or null
-    int accumulate;           // C += result
+// ---------------------------------------------------------------------------------------------------------------
+// geometry
+// ---------------------------------------------------------------------------------------------------------------
+struct Dims {
+    int E_p, E_d, F, H;          // nerf.py:49-59
+    int Pp, Dp, Fp, Hp;          // plane widths: padded to whole 32-feature blocks
+    int64_t w[11], b[11], total; // flat parameter blob, state_dict order
+    int in[11], out[11];
+    __host__ __device__ int recw() const { return Pp + Dp + 9 * Fp + Hp; }          // record floats per sample
+    __host__ __device__ int gradw() const { return 9 * Fp + Hp + 8 + Pp + Dp; }     // gradient planes, floats per sample
+    // record planes, float offset per sample (x MP)
+    __host__ __device__ int r_pe() const { return 0; }
+    __host__ __device__ int r_de() const { return Pp; }
+    __host__ __device__ int r_h(int l) const { return Pp + Dp + l * Fp; }           // h0..h7 (l = 8: y8)
+    __host__ __device__ int r_h9() const { return Pp + Dp + 9 * Fp; }
+    // gradient planes
+    __host__ __device__ int g_dy(int l) const { return l * Fp; }                    // dY0..dY7, dY8
+    __host__ __device__ int g_dy9() const { return 9 * Fp; }
+    __host__ __device__ int g_gy() const { return 9 * Fp + Hp; }                    // [sample][4], row-major
+    __host__ __device__ int g_dsig() const { return 9 * Fp + Hp + 4; }              // [sample] (4 reserved)
+    __host__ __device__ int g_gp() const { return 9 * Fp + Hp + 8; }
+    __host__ __device__ int g_gd() const { return 9 * Fp + Hp + 8 + Pp; }
+    // constant block (floats): fc_8.weight[0, :], fc_out.weight, 4 scalars, then one zero-padded bias row per layer
+    __host__ __device__ int c_w8row() const { return 0; }
+    __host__ __device__ int c_wout() const { return Fp; }                           // 3 rows of Hp
+    __host__ __device__ int c_scal() const { return Fp + 3 * Hp; }                  // fc_8.bias[0], fc_out.bias[0..2]
+    __host__ __device__ int c_bias(int l) const { return Fp + 3 * Hp + 4 + l * Fp; } // l = 0..9 (fc_8: rows 1..F)
+    __host__ __device__ int c_floats() const { return (Fp + 3 * Hp + 4 + 9 * Fp + Hp + 63) & ~63; }
 };
 
-__device__ __forceinline__ float load_a(const GemmArgs &g, int64_t i, int64_t k, int64_t k_end) {
-    if (i >= g.I || k >= k_end) return 0.0f;
-    return k < g.K1 ? g.A1[i * g.a1_si + k * g.a1_sk] : g.A2[i * g.a2_si + (k - g.K1) * g.a2_sk];
-}
-__device__ __forceinline__ float load_b(const GemmArgs &g, int64_t k, int j, int64_t k_end) {
-    if (j >= g.J || k >= k_end) return 0.0f;
-    return j == g.ones_col ? 1.0f : g.B[k * g.b_sk + (int64_t)j * g.b_sj];
-}
-
-// Workgroup tile (64 WI) x (64 WJ): 2 x 2 wavefronts, each (32 WI) x (32 WJ) = WI * WJ accumulator blocks.  The wider
-// tiles halve the LDS reads and the staging work per MFMA (a 64 x 64 tile reads two fragments per MFMA, a 128 x 128
-// tile one); the launcher picks the widest tile the output extent fills.
-template <int WI, int WJ>
-__global__ __launch_bounds__(256) void layered_gemm_kernel(const GemmArgs g) {
-    constexpr int TI_ = TI * WI, TJ_ = TJ * WJ;
-    __shared__ float As[TK][TI_ + 1], Bs[TK][TJ_ + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
-    const int64_t i0 = (int64_t)blockIdx.x * TI_;
-    const int j0 = blockIdx.y * TJ_;
-    const int64_t K = g.K1 + g.K2;
-    const int64_t k_begin = (int64_t)blockIdx.z * g.k_chunk;
-    const int64_t k_end = k_begin + g.k_chunk < K ? k_begin + g.k_chunk : K;
-
-    // thread -> (row, k) of the 4 WI (4 WJ) tile elements it stages of the A (B) operand
-    constexpr int NA = 4 * WI, NB = 4 * WJ;
-    int ar[NA], ak[NA], br[NB], bk[NB];
-#pragma unroll
-    for (int it = 0; it < NA; ++it) {
-        if (g.a_kfast) { ak[it] = tid & 15; ar[it] = (tid >> 4) + 16 * it; }
-        else           { ar[it] = tid % TI_; ak[it] = tid / TI_ + (256 / TI_) * it; }
+Dims make_dims(const nerf_net_t &d) {
+    Dims D;
+    D.E_p = d.pos_dim; D.E_d = d.view_dir_dim; D.F = d.feat_dim; D.H = d.feat_dim / 2;
+    D.Pp = ROUND32(D.E_p); D.Dp = ROUND32(D.E_d); D.Fp = ROUND32(D.F); D.Hp = ROUND32(D.H);
+    const int ins[11] = {D.E_p, D.F, D.F, D.F, D.F, D.F + D.E_p, D.F, D.F, D.F, D.F + D.E_d, D.H};
+    const int outs[11] = {D.F, D.F, D.F, D.F, D.F, D.F, D.F, D.F, D.F + 1, D.H, 3};
+    int64_t off = 0;
+    for (int l = 0; l < 11; ++l) {
+        D.in[l] = ins[l]; D.out[l] = outs[l];
+        D.w[l] = off; off += (int64_t)ins[l] * outs[l];
+        D.b[l] = off; off += outs[l];
     }
-#pragma unroll
-    for (int it = 0; it < NB; ++it) {
-        if (g.b_kfast) { bk[it] = tid & 15; br[it] = (tid >> 4) + 16 * it; }
-        else           { br[it] = tid % TJ_; bk[it] = tid / TJ_ + (256 / TJ_) * it; }
-    }
-    f32x16 acc[WI][WJ];
-#pragma unroll
-    for (int a = 0; a < WI; ++a)
-#pragma unroll
-        for (int b = 0; b < WJ; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    D.total = off;
+    return D;
+}
 
-    float ra[NA], rb[NB];
-    auto fetch = [&](int64_t kt) {
-#pragma unroll
-        for (int it = 0; it < NA; ++it) ra[it] = load_a(g, i0 + ar[it], kt + ak[it], k_end);
-#pragma unroll
-        for (int it = 0; it < NB; ++it) rb[it] = load_b(g, kt + bk[it], j0 + br[it], k_end);
-    };
-    if (k_begin < k_end) fetch(k_begin);
-    for (int64_t kt = k_begin; kt < k_end; kt += TK) {
-#pragma unroll
-        for (int it = 0; it < NA; ++it) As[ak[it]][ar[it]] = ra[it];
-#pragma unroll
-        for (int it = 0; it < NB; ++it) Bs[bk[it]][br[it]] = rb[it];
-        __syncthreads();
-        if (kt + TK < k_end) fetch(kt + TK);   // the next tile's loads fly under this tile's MFMAs
-#pragma unroll
-        for (int kk = 0; kk < TK / 2; ++kk) {
-            float fa[WI], fb[WJ];
-#pragma unroll
-            for (int a = 0; a < WI; ++a) fa[a] = As[2 * kk + (lane >> 5)][(wi * WI + a) * 32 + (lane & 31)];
-#pragma unroll
-            for (int b = 0; b < WJ; ++b) fb[b] = Bs[2 * kk + (lane >> 5)][(wj * WJ + b) * 32 + (lane & 31)];
-#pragma unroll
-            for (int a = 0; a < WI; ++a)
-#pragma unroll
-                for (int b = 0; b < WJ; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+// One pass: NFB accumulator blocks of one layer's output, all of its k.  Planes are named by (buffer, float offset per
+// sample, width); buffer 0 = the activation record, 1 = the gradient workspace.
+enum { INIT_ZERO = 0, INIT_BIAS = 1, INIT_DENSITY = 2 };
+enum { SIDE_NONE = 0, SIDE_DENSITY = 1, SIDE_FCOUT = 2 };
+struct Pass {
+    int nfb;                 // accumulator blocks computed: 2 | 4 | 8 (zero rows beyond `blocks`)
+    int blocks;              // blocks that exist in the destination window
+    int kb0, kb1;            // k-blocks of the two sources (torch.cat); kb1 = 0: one source
+    int src_buf0, src_buf1, src_off0, src_off1, src_w0, src_w1;   // (scalars, not arrays: hipcc parks a struct's arrays in scratch)
+    int dst_buf, dst_off, dst_w, dst_fb0;
+    int mask_off;            // record plane whose sign masks the result (reverse chain), -1: none; same window as dst
+    int init, init_off;      // INIT_*: constant-block offset of the bias window / the density row
+    int relu;
+    int side;
+    int first;               // first pass of its layer (side jobs that accumulate over passes start here)
+    int last;                // last pass of its layer
+    // weights: W[layer[s]] element (row, col); forward: out n -> row row0 + n, k -> col col0[s] + k;
+    // transposed (reverse chain): out n -> col col0[s] + n, k -> row row0 + k
+    int transposed, layer0, layer1, row0, rows_valid, col00, col01, cols_valid0, cols_valid1;
+    __host__ __device__ int chunks() const { const int kpc = 8 / nfb; return (kb0 + kb1 + kpc - 1) / kpc; }
+    __host__ __device__ int pairs() const { return (chunks() + 1) / 2; }
+};
+
+__host__ __device__ inline int pass_nfb(int blocks) { return blocks > 4 ? 8 : blocks > 2 ? 4 : 2; }
+
+// Forward program: layer by layer (nerf.py:102-119), each layer in passes of <= 8 output blocks.
+__host__ __device__ inline int fwd_layer_passes(const Dims &D, int l) { return ((l == 9 ? D.Hp : D.Fp) / 32 + 7) / 8; }
+__host__ __device__ inline int fwd_num_passes(const Dims &D) {
+    int n = 0;
+    for (int l = 0; l <= 9; ++l) n += fwd_layer_passes(D, l);
+    return n;
+}
+__host__ __device__ inline Pass fwd_pass(const Dims &D, int idx) {
+    int l = 0, j = idx;
+    while (j >= fwd_layer_passes(D, l)) { j -= fwd_layer_passes(D, l); ++l; }
+    const int nblk = (l == 9 ? D.Hp : D.Fp) / 32;
+    Pass P = {};
+    P.blocks = nblk - 8 * j < 8 ? nblk - 8 * j : 8;
+    P.nfb = pass_nfb(P.blocks);
+    P.dst_buf = 0; P.dst_fb0 = 8 * j; P.mask_off = -1;
+    P.dst_off = l == 9 ? D.r_h9() : D.r_h(l); P.dst_w = l == 9 ? D.Hp : D.Fp;
+    P.init = INIT_BIAS; P.init_off = D.c_bias(l) + 256 * j;
+    P.relu = l != 8;                                          // fc_8 has no ReLU (nerf.py:113)
+    P.first = j == 0; P.last = j + 1 == fwd_layer_passes(D, l);
+    P.side = l == 8 ? (j == 0 ? SIDE_DENSITY : SIDE_NONE) : l == 9 ? SIDE_FCOUT : SIDE_NONE;
+    P.transposed = 0; P.layer0 = P.layer1 = l;
+    P.row0 = l == 8 ? 1 : 0;                                  // row 0 of fc_8 is the density row
+    P.rows_valid = l == 9 ? D.H : D.F;
+    P.src_buf0 = P.src_buf1 = 0;
+    if (l == 0) {
+        P.kb0 = D.Pp / 32; P.src_off0 = D.r_pe(); P.src_w0 = D.Pp; P.col00 = 0; P.cols_valid0 = D.E_p;
+    } else if (l == 5) {   // cat([pos, x]) (:108)
+        P.kb0 = D.Pp / 32; P.src_off0 = D.r_pe(); P.src_w0 = D.Pp; P.col00 = 0; P.cols_valid0 = D.E_p;
+        P.kb1 = D.Fp / 32; P.src_off1 = D.r_h(4); P.src_w1 = D.Fp; P.col01 = D.E_p; P.cols_valid1 = D.F;
+    } else if (l == 9) {   // cat([x[:, 1:], view_dir]) (:116)
+        P.kb0 = D.Fp / 32; P.src_off0 = D.r_h(8); P.src_w0 = D.Fp; P.col00 = 0; P.cols_valid0 = D.F;
+        P.kb1 = D.Dp / 32; P.src_off1 = D.r_de(); P.src_w1 = D.Dp; P.col01 = D.F; P.cols_valid1 = D.E_d;
+    } else {
+        P.kb0 = D.Fp / 32; P.src_off0 = D.r_h(l - 1); P.src_w0 = D.Fp; P.col00 = 0; P.cols_valid0 = D.F;
+    }
+    return P;
+}
+
+// Reverse chain (autograd of nerf.py:102-119), after the vector prologue that makes dY9:
+//   stage 0: d y8[1:]  = W9[:, :F]^T dY9                       stage 1 (inputs): g_view_dir = W9[:, F:]^T dY9
+//   stage 2: dY7 = (W8[1:]^T d y8 + W8[0] dsigma') . [h7 > 0]  stages 3, 4: dY6, dY5
+//   stage 5: dY4 = (W5[:, E_p:]^T dY5) . [h4 > 0]              stages 6..9: dY3 .. dY0
+//   stage 10 (inputs): g_pos = W5[:, :E_p]^T dY5 + W_in^T dY0  (autograd adds the two shares as well)
+__host__ __device__ inline int dx_stage_blocks(const Dims &D, int st) { return (st == 1 ? D.Dp : st == 10 ? D.Pp : D.Fp) / 32; }
+__host__ __device__ inline int dx_stage_passes(const Dims &D, int st, int inputs) {
+    if ((st == 1 || st == 10) && !inputs) return 0;
+    return (dx_stage_blocks(D, st) + 7) / 8;
+}
+__host__ __device__ inline int dx_num_passes(const Dims &D, int inputs) {
+    int n = 0;
+    for (int st = 0; st <= 10; ++st) n += dx_stage_passes(D, st, inputs);
+    return n;
+}
+__host__ __device__ inline Pass dx_pass(const Dims &D, int inputs, int idx) {
+    int st = 0, j = idx;
+    while (j >= dx_stage_passes(D, st, inputs)) { j -= dx_stage_passes(D, st, inputs); ++st; }
+    const int nblk = dx_stage_blocks(D, st);
+    Pass P = {};
+    P.blocks = nblk - 8 * j < 8 ? nblk - 8 * j : 8;
+    P.nfb = pass_nfb(P.blocks);
+    P.dst_buf = 1; P.dst_fb0 = 8 * j; P.mask_off = -1; P.init = INIT_ZERO; P.relu = 0; P.side = SIDE_NONE;
+    P.first = j == 0; P.last = j + 1 == dx_stage_passes(D, st, inputs);
+    P.transposed = 1; P.src_buf0 = P.src_buf1 = 1;
+    if (st <= 1) {          // sources: dY9 (H outputs of fc_9)
+        P.kb0 = D.Hp / 32; P.src_off0 = D.g_dy9(); P.src_w0 = D.Hp;
+        P.layer0 = 9; P.row0 = 0; P.rows_valid = D.H;
+        if (st == 0) { P.dst_off = D.g_dy(8); P.dst_w = D.Fp; P.col00 = 0; P.cols_valid0 = D.F; }
+        else         { P.dst_off = D.g_gd(); P.dst_w = D.Dp; P.col00 = D.F; P.cols_valid0 = D.E_d; }
+    } else if (st == 10) {  // g_pos: two sources, two layers
+        P.kb0 = D.Fp / 32; P.src_off0 = D.g_dy(5); P.src_w0 = D.Fp; P.layer0 = 5;
+        P.kb1 = D.Fp / 32; P.src_off1 = D.g_dy(0); P.src_w1 = D.Fp; P.layer1 = 0;
+        P.row0 = 0; P.rows_valid = D.F; P.col00 = P.col01 = 0; P.cols_valid0 = P.cols_valid1 = D.E_p;
+        P.dst_off = D.g_gp(); P.dst_w = D.Pp;
+    } else {                // stage st = 2..9: layer l = 10 - st (8 .. 1): dY(l-1) from dY(l)
+        const int l = 10 - st;
+        P.kb0 = D.Fp / 32; P.src_off0 = D.g_dy(l); P.src_w0 = D.Fp; P.layer0 = l;
+        P.row0 = l == 8 ? 1 : 0; P.rows_valid = D.F;
+        P.col00 = l == 5 ? D.E_p : 0; P.cols_valid0 = D.F;
+        P.dst_off = D.g_dy(l - 1); P.dst_w = D.Fp;
+        P.mask_off = D.r_h(l - 1);
+        if (l == 8) { P.init = INIT_DENSITY; P.init_off = D.c_w8row() + 256 * j; }
+    }
+    return P;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// packing: constant block + the two weight streams, each pass a run of zero-padded slot-major pairs
+// ---------------------------------------------------------------------------------------------------------------
+struct PackArgs {
+    Dims D;
+    const float *P;
+    int dx, inputs;      // which program
+    int n_pairs;
+};
+
+__global__ void layered_pack_consts(const Dims D, const float *__restrict__ P, float *__restrict__ out) {
+    const int total = D.c_floats();
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (e < D.c_wout()) { if (e < D.F) v = P[D.w[8] + e]; }                               // fc_8.weight[0, :]
+        else if (e < D.c_scal()) { const int c = (e - D.c_wout()) / D.Hp, k = (e - D.c_wout()) % D.Hp; if (k < D.H) v = P[D.w[10] + c * D.H + k]; }
+        else if (e < D.c_scal() + 4) { const int c = e - D.c_scal(); v = c == 0 ? P[D.b[8]] : P[D.b[10] + c - 1]; }
+        else if (e < D.c_bias(9) + D.Hp) {
+            const int l = (e - D.c_bias(0)) / D.Fp, n = (e - D.c_bias(0)) % D.Fp;
+            if (l < 9) { if (n < D.F) v = P[D.b[l] + (l == 8 ? 1 : 0) + n]; }
+            else if (n < D.H) v = P[D.b[9] + n];
         }
-        __syncthreads();
+        out[e] = v;
     }
+}
 
-    // D fragment: register r of lane l is row (r&3) + 8 (r>>2) + 4 (l>>5), column l&31 of a 32 x 32 block
-    float *C = g.C + (int64_t)blockIdx.z * g.c_slice;
+__global__ void layered_pack_stream(const PackArgs a, float *__restrict__ out) {
+    // one workgroup per pair (grid-stride): find the pass that owns it (scalar walk, <= ~50 passes)
+    for (int pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x) {
+        int idx = 0, first = 0;
+        Pass P = a.dx ? dx_pass(a.D, a.inputs, 0) : fwd_pass(a.D, 0);
+        while (first + P.pairs() <= pair) {
+            first += P.pairs(); ++idx;
+            P = a.dx ? dx_pass(a.D, a.inputs, idx) : fwd_pass(a.D, idx);
+        }
+        const int kpc = 8 / P.nfb, total_kb = P.kb0 + P.kb1;
+        float *dst = out + (int64_t)pair * (PAIR_BYTES / 4);
+        for (int e = threadIdx.x; e < PAIR_BYTES / 4; e += blockDim.x) {
+            const int b = e * 4;                       // byte offset inside the pair
+            const int chunk = b >> 15, slot = (b >> 12) & 7, in_slot = b & 4095;
+            const int i = in_slot >> 7;                // row of the 32-row block
+            const int c = ((in_slot & 127) >> 4) ^ ((i >> 1) & 7);    // logical k-group (chunk_slot_offset's swizzle)
+            const int kk = 4 * c + ((in_slot & 15) >> 2);
+            const int kbi = ((pair - first) * 2 + chunk) * kpc + slot / P.nfb, fb = slot % P.nfb;
+            float v = 0.0f;
+            if (kbi < total_kb && fb < P.blocks) {
+                const int s = kbi < P.kb0 ? 0 : 1;
+                const int k = 32 * (s ? kbi - P.kb0 : kbi) + kk;       // index inside the source plane
+                const int n = 32 * (P.dst_fb0 + fb) + i;                 // index inside the destination plane
+                const int L = s ? P.layer1 : P.layer0, c0 = s ? P.col01 : P.col00, cv = s ? P.cols_valid1 : P.cols_valid0;
+                if (!P.transposed) {
+                    if (n < P.rows_valid && k < cv) v = a.P[a.D.w[L] + (int64_t)(P.row0 + n) * a.D.in[L] + c0 + k];
+                } else {
+                    if (k < P.rows_valid && n < cv) v = a.P[a.D.w[L] + (int64_t)(P.row0 + k) * a.D.in[L] + c0 + n];
+                }
+            }
+            dst[e] = v;
+        }
+    }
+}
+
+int stream_pairs(const Dims &D, int dx, int inputs) {
+    int n = 0;
+    const int np = dx ? dx_num_passes(D, inputs) : fwd_num_passes(D);
+    for (int p = 0; p < np; ++p) n += (dx ? dx_pass(D, inputs, p) : fwd_pass(D, p)).pairs();
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rows <-> planes
+// ---------------------------------------------------------------------------------------------------------------
+// plane[m][k] = k < E ? rows[m][k] : 0 for m < M, 0 for the padded rows (TF layout)
+__global__ void rows_to_plane_kernel(const float *__restrict__ rows, int64_t M, int64_t MP, int E, int W,
+                                     float *__restrict__ plane) {
+    const int64_t total = MP * W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        // e walks the plane in MEMORY order (coalesced stores): invert tf_offset
+        const int64_t tile = e / (32 * W);
+        const int r = (int)(e - tile * 32 * W);
+        const int slot = r >> 8, unit = ((r & 255) >> 2) ^ (2 * (slot & 3)), el = r & 3;
+        const int64_t m = tile * 32 + (unit >> 1);
+        const int k = 32 * (slot >> 2) + 8 * (slot & 3) + 4 * (unit & 1) + el;
+        plane[e] = (m < M && k < E) ? rows[m * E + k] : 0.0f;
+    }
+}
+__global__ void plane_to_rows_kernel(const float *__restrict__ plane, int64_t M, int E, int W, float *__restrict__ rows) {
+    const int64_t total = M * E;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = e / E;
+        rows[e] = plane[tf_offset(W, m, (int)(e - m * E))];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the persistent kernel
+// ---------------------------------------------------------------------------------------------------------------
+struct WideArgs {
+    Dims D;
+    const char *stream;      // weight pairs of this program
+    const float *consts;     // constant block
+    float *rec, *grad;       // buffer 0 / buffer 1 (plane = buffer + offset * MP)
+    int64_t M, MP;
+    int n_passes, n_pairs, inputs;
+    float *sigma, *rgb;                  // forward outputs
+    const float *sigma_in, *rgb_in, *g_sigma, *g_rgb;   // reverse chain inputs
+};
+
+// 16 bytes of this lane from a 4-KiB block: wave-uniform base + the lane's group offset + q * 1024.  A PLAIN load: the
+// first version issued these through inline asm (placement under control, no compiler waitcnt) -- and hipcc, which
+// believes an asm output valid at once, copied the destinations around before the data arrived and re-used the
+// registers of loads whose results a short pass never reads, which the late data then overwrote (memory faults
+// for feat_dim 64; scripts/audit_asm_loads.py now checks asm-issued global loads as well).  The compiler's own
+// waits for these loads sit at their first use, behind the pair's acquire, where nothing is outstanding any more.
+__device__ __forceinline__ f32x4 load16_s(const char *base, unsigned voff, int imm) {
+    return *reinterpret_cast<const f32x4 *>(base + voff + imm);
+}
+
+struct Ctx {
+    const char *lds;
+    int offq[4];
+    unsigned voff[4];        // byte offset of this lane's 16-byte group in slot q of a 4-KiB block: ((2 i + h) << 4) ^ (32 q)
+    int i, h;
+    int64_t row0;            // first sample of this wavefront in the current tile (multiple of 32)
+    int64_t m;               // this lane's sample
+    bool valid;
+};
+
+// this wavefront's 32-sample tile of a plane: base + (row0 / 32) * (32 * width floats)
+__device__ __forceinline__ const char *tile_of(const float *buf, int off, int width, int64_t MP, int64_t row0) {
+    return reinterpret_cast<const char *>(buf + (int64_t)off * MP + row0 * width);
+}
+
+// B operands of one PAIR of the pass (2 * KPC k-blocks starting at k-block kb_first).  k-blocks past the pass's end
+// re-read the last block: their weights are zero slots of the stream and every plane holds finite values.
+template <int KPC>
+__device__ __forceinline__ void load_b_pair(f32x16 (&b)[2 * KPC], const Pass &P, int kb_first, const char *src0,
+                                            const char *src1, const Ctx &c) {
+    const int total = P.kb0 + P.kb1;
 #pragma unroll
-    for (int b = 0; b < WJ; ++b) {
-        const int j = j0 + (wj * WJ + b) * 32 + (lane & 31);
-        if (j >= g.J) continue;
-        const float bj = g.bias ? g.bias[j] : 0.0f;
+    for (int j = 0; j < 2 * KPC; ++j) {
+        int kb = kb_first + j;       // wave-uniform
+        if (kb >= total) kb = total - 1;
+        const char *base = kb < P.kb0 ? src0 + (size_t)kb * 4096 : src1 + (size_t)(kb - P.kb0) * 4096;
 #pragma unroll
-        for (int a = 0; a < WI; ++a)
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = load16_s(base, c.voff[q], q * 1024);
+            b[j][4 * q + 0] = v.x; b[j][4 * q + 1] = v.y; b[j][4 * q + 2] = v.z; b[j][4 * q + 3] = v.w;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the loads stay here, a pair ahead of their use
+}
+
+// One pass over the current tile.  DX: the reverse-chain flavour (ReLU masks from the record, density-row init).
+// pr0..pr2 carry the fc_out partial dot products across the passes of fc_9; `sig` the density pre-activation.
+template <int NFB, bool DX>
+__device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const Ctx &c, Pipe &pipe, float &pr0,
+                                         float &pr1, float &pr2, float &sig, float dsig) {
+    constexpr int KPC = 8 / NFB;
+    const float *sbuf0 = P.src_buf0 ? a.grad : a.rec, *sbuf1 = P.src_buf1 ? a.grad : a.rec;
+    const char *src0 = tile_of(sbuf0, P.src_off0, P.src_w0, a.MP, c.row0);
+    const char *src1 = tile_of(sbuf1, P.src_off1, P.src_w1, a.MP, c.row0);
+    const int pairs = P.pairs(), chunks = P.chunks();
+
+    f32x16 bA[2 * KPC], bB[2 * KPC];
+    // the sources were stored by this very wavefront one pass ago (asm-issued stores): drain them, then read back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    load_b_pair<KPC>(bA, P, 0, src0, src1, c);
+
+    f32x16 acc[NFB];
+    {   // initial accumulators: bias window / density row x dsigma' / zero (all rows of the constant block are padded)
+        const float *row = a.consts + P.init_off;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t i = i0 + (wi * WI + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (i >= g.I) continue;
-                float v = acc[a][b][r] + bj;
-                if (g.act == 1) v = v > 0.0f ? v : 0.0f;
-                else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
-                if (g.mask) v = g.mask[i * g.mask_si + j] > 0.0f ? v : 0.0f;
-                float *dst = C + i * g.c_si + j;
-                *dst = g.accumulate ? *dst + v : v;
+        for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (P.init != INIT_ZERO && fb < P.blocks) v = *reinterpret_cast<const f32x4 *>(row + 32 * fb + 8 * q + 4 * c.h);
+                const float s = (DX && P.init == INIT_DENSITY) ? dsig : 1.0f;
+                acc[fb][4 * q + 0] = v.x * s; acc[fb][4 * q + 1] = v.y * s;
+                acc[fb][4 * q + 2] = v.z * s; acc[fb][4 * q + 3] = v.w * s;
             }
     }
-}
+    if (!DX && P.side == SIDE_DENSITY) sig = 0.0f;
 
-// dst[i * w_si + j] = sum_z partial[z][i][j] (j < Jw), bias[i] = sum_z partial[z][i][Jw] (if bias), slices in order
-__global__ void layered_reduce_kernel(const float *__restrict__ partial, int slices, int I, int J, int Jw,
-                                      float *__restrict__ w, int64_t w_si, float *__restrict__ bias) {
-    const int64_t total = (int64_t)I * J;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(e / J), j = (int)(e % J);
-        float s = 0.0f;
-        for (int z = 0; z < slices; ++z) s += partial[(int64_t)z * total + e];
-        if (j < Jw) w[i * w_si + j] = s;
-        else if (bias) bias[i] = s;
-    }
-}
+    f32x16 mk[NFB];          // DX: the forward activations whose sign masks this pass's result
+    const bool masked = DX && P.mask_off >= 0;
+    const char *mtile = masked ? tile_of(a.rec, P.mask_off, P.dst_w, a.MP, c.row0) + (size_t)P.dst_fb0 * 4096 : nullptr;
 
-// sigma = relu(y8[:, 0])   (nerf.py:115)
-__global__ void layered_sigma_kernel(const float *__restrict__ y8, int64_t ld, int64_t M, float *__restrict__ sigma) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < M) {
-        const float v = y8[m * ld];
-        sigma[m] = v > 0.0f ? v : 0.0f;
-    }
-}
-
-// reverse of the two output non-linearities (nerf.py:115, :119): g10 = g_rgb * rgb * (1 - rgb); gy8[:, 0] = g_sigma . [sigma > 0]
-__global__ void layered_heads_bwd_kernel(const float *__restrict__ sigma, const float *__restrict__ rgb,
-                                         const float *__restrict__ g_sigma, const float *__restrict__ g_rgb, int64_t M,
-                                         float *__restrict__ g10, float *__restrict__ gy8, int64_t ld8) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+    // the density row of fc_8 rides on the B operands streaming by (nerf.py:113-115): sigma' = W8[0, :] . h7 + b
+    auto density = [&](const f32x16 (&b)[2 * KPC], int kb_first) {
+        const float *w8 = a.consts + a.D.c_w8row();
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float y = rgb[3 * m + c];
-        g10[3 * m + c] = g_rgb[3 * m + c] * y * (1.0f - y);
-    }
-    gy8[m * ld8] = sigma[m] > 0.0f ? g_sigma[m] : 0.0f;
-}
-
-struct Layout {          // flat parameter blob, state_dict order
-    int E_p, E_d, F, H;
-    int in[11], out[11];
-    int64_t w[11], b[11], total;
-    explicit Layout(const nerf_net_t &d) : E_p(d.pos_dim), E_d(d.view_dir_dim), F(d.feat_dim), H(d.feat_dim / 2) {
-        const int ins[11] = {E_p, F, F, F, F, F + E_p, F, F, F, F + E_d, H};
-        const int outs[11] = {F, F, F, F, F, F, F, F, F + 1, H, 3};
-        int64_t off = 0;
-        for (int l = 0; l < 11; ++l) {
-            in[l] = ins[l]; out[l] = outs[l];
-            w[l] = off; off += (int64_t)ins[l] * outs[l];
-            b[l] = off; off += outs[l];
+        for (int j = 0; j < 2 * KPC; ++j) {
+            const int kb = kb_first + j;
+            if (kb < P.kb0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(w8 + 32 * kb + 8 * q + 4 * c.h);
+                    sig = fmaf(w.x, b[j][4 * q + 0], sig); sig = fmaf(w.y, b[j][4 * q + 1], sig);
+                    sig = fmaf(w.z, b[j][4 * q + 2], sig); sig = fmaf(w.w, b[j][4 * q + 3], sig);
+                }
+            }
         }
-        total = off;
-    }
-    int64_t record_floats_per_row() const { return 8 * (int64_t)F + (F + 1) + H; }   // h0..h7, y8, h9
-};
-
-struct Record {          // row-major planes of `rows` rows
-    float *h[8], *y8, *h9;
-    Record(float *base, int64_t rows, const Layout &L) {
-        for (int l = 0; l < 8; ++l) h[l] = base + rows * (int64_t)L.F * l;
-        y8 = base + rows * (int64_t)L.F * 8;
-        h9 = y8 + rows * (int64_t)(L.F + 1);
-    }
-};
-
-GemmArgs blank() {
-    GemmArgs g = {};
-    g.ones_col = -1;
-    return g;
-}
-
-// Tile shape.  The kernel is templated on 64- or 128-wide tiles per direction; the 128-wide ones (two accumulator
-// blocks per wavefront and direction, half the LDS reads per MFMA) were measured and are SLOWER -- 60 / 43 instead of
-// 61.5 / 53 TFLOP/s forward / backward at feat_dim 256 -- because the kernel is bound by its bounds-checked scalar
-// staging loads, which the 64 x 64 tile hides behind four workgroups per CU.  So: 64 x 64 everywhere.
-#ifdef X_LAYERED_WIDE
-inline int tile_i(int I) { return I >= 128 ? 128 : 64; }
-inline int tile_j(int J) { return J >= 128 ? 128 : 64; }
-#else
-inline int tile_i(int) { return 64; }
-inline int tile_j(int) { return 64; }
-#endif
-
-int launch(const GemmArgs &g, int slices, hipStream_t s, const char *what) {
-    if (g.I <= 0 || g.J <= 0) return NERF_OK;
-    const int ti = tile_i(g.I), tj = tile_j(g.J);
-    const dim3 grid((unsigned)((g.I + ti - 1) / ti), (unsigned)((g.J + tj - 1) / tj), (unsigned)slices);
-    if (ti == 128 && tj == 128) hipLaunchKernelGGL((layered_gemm_kernel<2, 2>), grid, dim3(256), 0, s, g);
-    else if (ti == 128) hipLaunchKernelGGL((layered_gemm_kernel<2, 1>), grid, dim3(256), 0, s, g);
-    else if (tj == 128) hipLaunchKernelGGL((layered_gemm_kernel<1, 2>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((layered_gemm_kernel<1, 1>), grid, dim3(256), 0, s, g);
-    return nerf::check_launch(what);
-}
-
-// Y[rows, N] = act(cat(X1, X2) W^T + b): nn.Linear (+ torch.cat of its two inputs) + activation
-int linear_fwd(const float *P, const Layout &L, int layer, const float *X1, int64_t ld1, int K1, const float *X2,
-               int64_t ld2, int K2, int64_t rows, float *Y, int64_t ldy, int act, hipStream_t s) {
-    GemmArgs g = blank();
-    g.A1 = X1; g.a1_si = ld1; g.a1_sk = 1; g.K1 = K1;
-    g.A2 = X2; g.a2_si = ld2; g.a2_sk = 1; g.K2 = K2;
-    g.B = P + L.w[layer]; g.b_sk = 1; g.b_sj = L.in[layer];       // B(k, n) = W[n][k]
-    g.I = (int)rows; g.J = L.out[layer];
-    g.a_kfast = 1; g.b_kfast = 1;
-    g.k_chunk = K1 + K2; g.c_slice = 0;
-    g.C = Y; g.c_si = ldy; g.bias = P + L.b[layer]; g.act = act;
-    return launch(g, 1, s, "nerf_mlp_layered_forward: layer");
-}
-
-// dX[rows, K] (+)= (G[rows, N] W[:, col0 : col0 + K]) . [mask > 0]
-int linear_dx(const float *P, const Layout &L, int layer, const float *G, int64_t ldg, int64_t rows, int col0, int K,
-              float *dX, int64_t ldx, const float *mask, int64_t ldm, int accumulate, hipStream_t s) {
-    GemmArgs g = blank();
-    g.A1 = G; g.a1_si = ldg; g.a1_sk = 1; g.K1 = L.out[layer];    // reduction over the layer's outputs
-    g.B = P + L.w[layer] + col0; g.b_sk = L.in[layer]; g.b_sj = 1;  // B(n, k) = W[n][col0 + k]
-    g.I = (int)rows; g.J = K;
-    g.a_kfast = 1; g.b_kfast = 0;
-    g.k_chunk = g.K1; g.c_slice = 0;
-    g.C = dX; g.c_si = ldx; g.mask = mask; g.mask_si = ldm; g.accumulate = accumulate;
-    return launch(g, 1, s, "nerf_mlp_layered_backward: dX");
-}
-
-// fixed slicing of the sample axis (a function of M and the tile grid only: never of the device)
-int dw_slices(int64_t M, int I, int J) {
-    const int64_t tiles = (int64_t)((I + tile_i(I) - 1) / tile_i(I)) * ((J + tile_j(J) - 1) / tile_j(J));
-    int64_t want = (1024 + tiles - 1) / tiles;
-    const int64_t most = (M + 511) / 512;          // at least 512 rows per slice
-    if (want > most) want = most;
-    if (want > 256) want = 256;
-    return (int)(want < 1 ? 1 : want);
-}
-
-// dW[:, col0 : col0 + K] = G^T X (and db = column sums of G when with_bias), through `partial`
-int linear_dw(float *GP, const Layout &L, int layer, const float *G, int64_t ldg, const float *X, int64_t ldx,
-              int64_t M, int col0, int K, bool with_bias, float *partial, hipStream_t s) {
-    const int I = L.out[layer], J = K + (with_bias ? 1 : 0);
-    const int slices = dw_slices(M, I, J);
-    GemmArgs g = blank();
-    g.A1 = G; g.a1_si = 1; g.a1_sk = ldg; g.K1 = M;               // A(n, m) = G[m][n]
-    g.B = X; g.b_sk = ldx; g.b_sj = 1;                            // B(m, k) = X[m][k]
-    g.I = I; g.J = J; g.ones_col = with_bias ? K : -1;
-    g.a_kfast = 0; g.b_kfast = 0;
-    g.k_chunk = ((M + slices - 1) / slices + TK - 1) / TK * TK;
-    g.c_slice = (int64_t)I * J;
-    g.C = partial; g.c_si = J;
-    if (int rc = launch(g, slices, s, "nerf_mlp_layered_backward: dW")) return rc;
-    const int64_t total = (int64_t)I * J;
-    hipLaunchKernelGGL(layered_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)),
-                       dim3(256), 0, s, partial, slices, I, J, K, GP + L.w[layer] + col0, (int64_t)L.in[layer],
-                       with_bias ? GP + L.b[layer] : nullptr);
-    return nerf::check_launch("nerf_mlp_layered_backward: reduce");
-}
-
-int64_t align64(int64_t floats) { return (floats + 63) & ~(int64_t)63; }
-
-int64_t partial_floats(const Layout &L) {   // the largest slices * I * J over the dW calls of the backward, for any M
-    int64_t most = 0;
-    auto piece = [&](int I, int J) {
-        const int64_t tiles = (int64_t)((I + tile_i(I) - 1) / tile_i(I)) * ((J + tile_j(J) - 1) / tile_j(J));
-        int64_t s = (1024 + tiles - 1) / tiles;
-        if (s > 256) s = 256;
-        if (s * I * J > most) most = s * (int64_t)I * J;
     };
-    for (int l = 0; l < 11; ++l) {
-        if (l == 5) { piece(L.out[l], L.E_p); piece(L.out[l], L.F + 1); }          // (the bias column counts)
-        else if (l == 9) { piece(L.out[l], L.F + 1); piece(L.out[l], L.E_d); }
-        else piece(L.out[l], L.in[l] + 1);
+
+    for (int pr = 0; pr < pairs; pr += 2) {
+        {   // even pair: operands bA, next pair's into bB
+            const char *w = c.lds + pipe.acquire();
+            if (pr + 1 < pairs) load_b_pair<KPC>(bB, P, (pr + 1) * 2 * KPC, src0, src1, c);
+            if (masked && pr + 1 >= pairs) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb)
+                    if (fb < P.blocks) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = load16_s(mtile + fb * 4096, c.voff[q], q * 1024);
+                            mk[fb][4 * q + 0] = v.x; mk[fb][4 * q + 1] = v.y; mk[fb][4 * q + 2] = v.z; mk[fb][4 * q + 3] = v.w;
+                        }
+                    }
+            }
+            if (!DX && P.side == SIDE_DENSITY) density(bA, pr * 2 * KPC);
+            mma_slots<NFB, KPC, 0, 16>(acc, bA, w, c.offq, &pipe);
+            if (2 * pr + 1 < chunks) mma_slots<NFB, KPC>(acc, bA + KPC, w + CHUNK_BYTES, c.offq);
+            pipe.issue_done();
+        }
+        if (pr + 1 < pairs) {   // odd pair: operands bB, next pair's into bA
+            const char *w = c.lds + pipe.acquire();
+            if (pr + 2 < pairs) load_b_pair<KPC>(bA, P, (pr + 2) * 2 * KPC, src0, src1, c);
+            if (masked && pr + 2 >= pairs) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb)
+                    if (fb < P.blocks) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = load16_s(mtile + fb * 4096, c.voff[q], q * 1024);
+                            mk[fb][4 * q + 0] = v.x; mk[fb][4 * q + 1] = v.y; mk[fb][4 * q + 2] = v.z; mk[fb][4 * q + 3] = v.w;
+                        }
+                    }
+            }
+            if (!DX && P.side == SIDE_DENSITY) density(bB, (pr + 1) * 2 * KPC);
+            mma_slots<NFB, KPC, 0, 16>(acc, bB, w, c.offq, &pipe);
+            if (2 * pr + 3 < chunks) mma_slots<NFB, KPC>(acc, bB + KPC, w + CHUNK_BYTES, c.offq);
+            pipe.issue_done();
+        }
     }
-    return most;
+
+    // ---- epilogue
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[fb][r];
+            if (P.relu) v = relu1(v);
+            if (masked) v = mk[fb][r] > 0.0f ? v : 0.0f;
+            acc[fb][r] = v;
+        }
+    float *dbuf = P.dst_buf ? a.grad : a.rec;
+    float *dplane = dbuf + (int64_t)P.dst_off * a.MP + (int64_t)P.dst_fb0 * 1024;
+    // (block counts are wave-uniform: whole store groups are skipped for blocks the plane does not have)
+    if (P.blocks >= NFB) save_plane<NFB, true>(dplane, P.dst_w, c.m, c.h, acc);
+    else {
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb)
+            if (fb < P.blocks) save_plane<1, true>(dplane + fb * 1024, P.dst_w, c.m, c.h, acc + fb);
+    }
+    if (!DX && P.side == SIDE_DENSITY) {
+        float s = sig + __shfl_xor(sig, 32, WAVE);
+        s = fmaxf(s + a.consts[a.D.c_scal()], 0.0f);           // relu(x[:, 0]) (nerf.py:115)
+        if (c.valid && c.h == 0) a.sigma[c.m] = s;
+    }
+    if (!DX && P.side == SIDE_FCOUT) {   // rgb = sigmoid(fc_out(h9)) (nerf.py:119), partial dots over the passes of fc_9
+        // (three scalars: an array handed through the three instantiations of this function ends up in scratch)
+        if (P.first) pr0 = pr1 = pr2 = 0.0f;
+        const float *w = a.consts + a.D.c_wout() + 32 * P.dst_fb0;
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb)
+            if (fb < P.blocks) {
+                pr0 += block_dot(w + 32 * fb, acc[fb], c.h);
+                pr1 += block_dot(w + a.D.Hp + 32 * fb, acc[fb], c.h);
+                pr2 += block_dot(w + 2 * a.D.Hp + 32 * fb, acc[fb], c.h);
+            }
+        if (P.last) {
+            const float *bo = a.consts + a.D.c_scal() + 1;
+            const float y0 = 1.0f / (1.0f + expf(-(pr0 + __shfl_xor(pr0, 32, WAVE) + bo[0])));
+            const float y1 = 1.0f / (1.0f + expf(-(pr1 + __shfl_xor(pr1, 32, WAVE) + bo[1])));
+            const float y2 = 1.0f / (1.0f + expf(-(pr2 + __shfl_xor(pr2, 32, WAVE) + bo[2])));
+            if (c.valid && c.h == 0) { a.rgb[3 * c.m] = y0; a.rgb[3 * c.m + 1] = y1; a.rgb[3 * c.m + 2] = y2; }
+        }
+    }
 }
+
+template <bool DX>
+__global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Ctx c;
+    c.lds = lds;
+    c.i = lane & 31; c.h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        c.offq[q] = chunk_slot_offset(c.i, 2 * q + c.h);
+        c.voff[q] = ((unsigned)(2 * c.i + c.h) << 4) ^ (32u * q);
+    }
+    Pipe pipe;
+    pipe.src_wave = a.stream + wave * 8192;
+    pipe.lane_off = (unsigned)lane * 16u;
+    pipe.lds_wave = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 8192u;
+    pipe.issued = 0; pipe.issue_pos = 0; pipe.consumed = 0;
+    pipe.n_pairs = a.n_pairs; pipe.skip_mask = 0;
+    __syncthreads();
+    pipe.issue();
+
+    const int64_t ntiles = a.MP / TILE_SAMPLES;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        c.row0 = tile * TILE_SAMPLES + wave * 32;
+        c.m = c.row0 + c.i;
+        c.valid = c.m < a.M;
+        float pr0 = 0.0f, pr1 = 0.0f, pr2 = 0.0f, sig = 0.0f, dsig = 0.0f;
+        if (DX) {
+            // ---- heads (nerf.py:115, :119): d y10 = g_rgb rgb (1 - rgb), dsigma' = g_sigma . [sigma > 0]; then
+            // dY9 = (W_out^T d y10) . [h9 > 0] on the vector ALU, block by block
+            const int64_t mc = c.valid ? c.m : a.M - 1;
+            float gy[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float y = a.rgb_in[3 * mc + ch];
+                gy[ch] = c.valid ? a.g_rgb[3 * mc + ch] * y * (1.0f - y) : 0.0f;
+            }
+            dsig = (c.valid && a.sigma_in[mc] > 0.0f) ? a.g_sigma[mc] : 0.0f;
+            if (c.h == 0) {
+                const f32x4 g4 = {gy[0], gy[1], gy[2], 0.0f};
+                *reinterpret_cast<f32x4 *>(a.grad + (int64_t)a.D.g_gy() * a.MP + 4 * c.m) = g4;
+                a.grad[(int64_t)a.D.g_dsig() * a.MP + c.m] = dsig;
+            }
+            const float *wout = a.consts + a.D.c_wout();
+            const float *h9 = a.rec + (int64_t)a.D.r_h9() * a.MP + c.row0 * a.D.Hp;
+            float *d9 = a.grad + (int64_t)a.D.g_dy9() * a.MP;
+            for (int fb = 0; fb < a.D.Hp / 32; ++fb) {
+                f32x16 x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k0 = 32 * fb + 8 * q + 4 * c.h;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wout + k0);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wout + a.D.Hp + k0);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4 *>(wout + 2 * a.D.Hp + k0);
+                    const f32x4 hv = *reinterpret_cast<const f32x4 *>(h9 + (fb * 4 + q) * 256 + 4 * ((2 * c.i + c.h) ^ (2 * q)));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = fmaf(w2[j], gy[2], fmaf(w1[j], gy[1], w0[j] * gy[0]));
+                        x[4 * q + j] = hv[j] > 0.0f ? v : 0.0f;
+                    }
+                }
+                save_plane<1, true>(d9 + fb * 1024, a.D.Hp, c.m, c.h, &x);
+            }
+        }
+        for (int p = 0; p < a.n_passes; ++p) {
+            const Pass P = DX ? dx_pass(a.D, a.inputs, p) : fwd_pass(a.D, p);
+            if (P.nfb == 8) run_pass<8, DX>(P, a, c, pipe, pr0, pr1, pr2, sig, dsig);
+            else if (P.nfb == 4) run_pass<4, DX>(P, a, c, pipe, pr0, pr1, pr2, sig, dsig);
+            else run_pass<2, DX>(P, a, c, pipe, pr0, pr1, pr2, sig, dsig);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// thin reductions of the reverse pass (vector ALU, HBM-bound: one more read of the h7 and h9 planes):
+//   fc_8.weight[0, k] = sum_m dsig[m] h7[m][k],  fc_out.weight[c][k] = sum_m gy[m][c] h9[m][k],
+//   fc_8.bias[0] = sum dsig,  fc_out.bias[c] = sum gy[.][c]
+// grid.y slices of the sample axis write partials; a second kernel adds them in order (deterministic).
+constexpr int THIN_SLICES = 64;
+__global__ void layered_thin_kernel(const Dims D, const float *__restrict__ rec, const float *__restrict__ grad,
+                                    int64_t M, int64_t MP, float *__restrict__ partial) {
+    const int cols = D.Fp + 3 * D.Hp + 4;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    const int64_t per = (M + gridDim.y - 1) / gridDim.y, m0 = blockIdx.y * per, m1 = m0 + per < M ? m0 + per : M;
+    const float *gy = grad + (int64_t)D.g_gy() * MP, *ds = grad + (int64_t)D.g_dsig() * MP;
+    float s = 0.0f;
+    if (col < D.Fp) {
+        const float *h7 = rec + (int64_t)D.r_h(7) * MP;
+        for (int64_t m = m0; m < m1; ++m) s = fmaf(ds[m], h7[tf_offset(D.Fp, m, col)], s);
+    } else if (col < D.Fp + 3 * D.Hp) {
+        const int ch = (col - D.Fp) / D.Hp, k = (col - D.Fp) % D.Hp;
+        const float *h9 = rec + (int64_t)D.r_h9() * MP;
+        for (int64_t m = m0; m < m1; ++m) s = fmaf(gy[4 * m + ch], h9[tf_offset(D.Hp, m, k)], s);
+    } else {
+        const int ch = col - D.Fp - 3 * D.Hp;
+        for (int64_t m = m0; m < m1; ++m) s += ch == 0 ? ds[m] : gy[4 * m + ch - 1];
+    }
+    partial[(int64_t)blockIdx.y * cols + col] = s;
+}
+__global__ void layered_thin_reduce_kernel(const Dims D, const float *__restrict__ partial, int slices,
+                                           float *__restrict__ g_params) {
+    const int cols = D.Fp + 3 * D.Hp + 4;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    float s = 0.0f;
+    for (int z = 0; z < slices; ++z) s += partial[(int64_t)z * cols + col];
+    if (col < D.Fp) { if (col < D.F) g_params[D.w[8] + col] = s; }
+    else if (col < D.Fp + 3 * D.Hp) {
+        const int ch = (col - D.Fp) / D.Hp, k = (col - D.Fp) % D.Hp;
+        if (k < D.H) g_params[D.w[10] + ch * D.H + k] = s;
+    } else {
+        const int ch = col - D.Fp - 3 * D.Hp;
+        g_params[ch == 0 ? D.b[8] : D.b[10] + ch - 1] = s;
+    }
+}
+
+inline int64_t align256b(int64_t b) { return (b + 255) & ~(int64_t)255; }
+
+// buffer layouts (bytes)
+struct Sizes {
+    int64_t consts, fwd_stream, dx_stream, planes;   // planes: record (forward) or gradient planes (backward)
+};
+Sizes sizes(const Dims &D, int64_t rows, bool backward, int inputs) {
+    Sizes s;
+    s.consts = align256b(4 * (int64_t)D.c_floats());
+    s.fwd_stream = (int64_t)stream_pairs(D, 0, 0) * PAIR_BYTES;
+    s.dx_stream = backward ? (int64_t)stream_pairs(D, 1, inputs) * PAIR_BYTES : 0;
+    s.planes = align256b(4 * padded_rows(rows) * (int64_t)(backward ? D.gradw() : D.recw()));
+    return s;
+}
+
+int launch_program(bool dx, const WideArgs &a, hipStream_t s) {
+    auto kern = dx ? layered_kernel<true> : layered_kernel<false>;
+    static nerf::DeviceMask configured[2] = {{0}, {0}};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), RING_SLOTS * CHUNK_BYTES, configured[dx],
+                                          "nerf_mlp_layered: LDS attribute"))
+        return rc;
+    const int64_t ntiles = a.MP / TILE_SAMPLES;
+    const int cus = nerf::device_cus();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(256), RING_SLOTS * CHUNK_BYTES, s, a);
+    return nerf::check_launch(dx ? "nerf_mlp_layered_backward: reverse chain" : "nerf_mlp_layered_forward");
+}
+
+unsigned grid_for(int64_t total) { return (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192); }
 
 }  // namespace
 
+// record buffer = [constant block][forward stream][planes of `rows` rows]
 NERF_API int64_t nerf_mlp_layered_record_bytes(const nerf_net_t *net, int64_t rows) {
     nerf_net_t d;
     if (nerf::net_describe(net, d) < 0) return -1;
-    return rows <= 0 ? 0 : 4 * rows * Layout(d).record_floats_per_row();
+    if (rows <= 0) return 0;
+    const Dims D = make_dims(d);
+    const Sizes z = sizes(D, rows, false, 0);
+    return z.consts + z.fwd_stream + z.planes;
 }
 
+// Where a plane of the record sits (for tools and tests; the record is otherwise opaque): which = 0 encoded position,
+// 1 encoded direction, 2..9 h0..h7 (post-ReLU), 10 fc_8 rows 1..F (no ReLU), 11 h9.  Returns the byte offset inside a
+// record of `rows` rows and the plane's padded width (floats per sample, tile-fragment layout: nerf_mlp_plane_offset).
+NERF_API int64_t nerf_mlp_layered_plane(const nerf_net_t *net, int64_t rows, int which, int *width) {
+    nerf_net_t d;
+    if (nerf::net_describe(net, d) < 0 || rows <= 0 || which < 0 || which > 11) return -1;
+    const Dims D = make_dims(d);
+    const Sizes z = sizes(D, rows, false, 0);
+    const int off = which == 0 ? D.r_pe() : which == 1 ? D.r_de() : which == 11 ? D.r_h9() : D.r_h(which - 2);
+    if (width) *width = which == 0 ? D.Pp : which == 1 ? D.Dp : which == 11 ? D.Hp : D.Fp;
+    return z.consts + z.fwd_stream + 4 * (int64_t)off * padded_rows(rows);
+}
+
+// workspace = [reverse stream (with the input-gradient passes)][gradient planes][thin partials][dW scratch]
 NERF_API int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t M) {
     nerf_net_t d;
     if (nerf::net_describe(net, d) < 0) return -1;
     if (M <= 0) return 0;
-    const Layout L(d);
-    // two ping-pong gradient planes (M, F+1), dY9 (M, F/2), d y10 (M, 3), partial dW tiles
-    return 4 * (2 * align64(M * (int64_t)(L.F + 1)) + align64(M * (int64_t)L.H) + align64(M * 3) + align64(partial_floats(L)));
+    const Dims D = make_dims(d);
+    const Sizes z = sizes(D, M, true, 1);
+    const int64_t thin = align256b(4 * (int64_t)THIN_SLICES * (D.Fp + 3 * D.Hp + 4));
+    const int items = 64 * ((D.Fp + 255) / 256) * ((D.Fp + 255) / 256) + 64;
+    return z.dx_stream + z.planes + thin + nerf::dw_items_scratch_bytes(items) + 65536;
 }
 
 NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params, const float *pos,
@@ -337,31 +688,33 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
     NERF_REQUIRE(params && pos && view_dir && sigma && rgb && record && record_rows > 0,
                  "nerf_mlp_layered_forward: null pointer");
     NERF_REQUIRE(M < (int64_t)1 << 31, "nerf_mlp_layered_forward: more than 2^31 samples per call");
-    const Layout L(d);
+    const Dims D = make_dims(d);
     hipStream_t s = nerf::as_stream(stream);
     const int64_t chunk = record_rows < M ? record_rows : M;
-    const Record R(static_cast<float *>(record), chunk, L);
-    const int F = L.F, E_p = L.E_p, E_d = L.E_d;
+    const Sizes z = sizes(D, chunk, false, 0);
+    char *base = static_cast<char *>(record);
+    float *consts = reinterpret_cast<float *>(base);
+    float *fstream = reinterpret_cast<float *>(base + z.consts);
+    float *planes = reinterpret_cast<float *>(base + z.consts + z.fwd_stream);
+    // pack (once per call: the parameters may have changed; 2 x the parameter bytes of HBM traffic)
+    hipLaunchKernelGGL(layered_pack_consts, dim3(grid_for(D.c_floats())), dim3(256), 0, s, D, params, consts);
+    PackArgs pa; pa.D = D; pa.P = params; pa.dx = 0; pa.inputs = 0; pa.n_pairs = stream_pairs(D, 0, 0);
+    hipLaunchKernelGGL(layered_pack_stream, dim3((unsigned)(pa.n_pairs < 1024 ? pa.n_pairs : 1024)), dim3(256), 0, s, pa, fstream);
+    if (int rc = nerf::check_launch("nerf_mlp_layered_forward: pack")) return rc;
     for (int64_t r0 = 0; r0 < M; r0 += chunk) {
         const int64_t rows = M - r0 < chunk ? M - r0 : chunk;
-        const float *x = pos + r0 * E_p, *v = view_dir + r0 * E_d;
-        int rc;
-        // nerf.py:102-106
-        if ((rc = linear_fwd(params, L, 0, x, E_p, E_p, nullptr, 0, 0, rows, R.h[0], F, 1, s))) return rc;
-        for (int l = 1; l <= 4; ++l)
-            if ((rc = linear_fwd(params, L, l, R.h[l - 1], F, F, nullptr, 0, 0, rows, R.h[l], F, 1, s))) return rc;
-        // :108-110  cat([pos, x]) -- pos first
-        if ((rc = linear_fwd(params, L, 5, x, E_p, E_p, R.h[4], F, F, rows, R.h[5], F, 1, s))) return rc;
-        for (int l = 6; l <= 7; ++l)
-            if ((rc = linear_fwd(params, L, l, R.h[l - 1], F, F, nullptr, 0, 0, rows, R.h[l], F, 1, s))) return rc;
-        // :113-115  fc_8 has no ReLU; sigma = relu(x[:, 0])
-        if ((rc = linear_fwd(params, L, 8, R.h[7], F, F, nullptr, 0, 0, rows, R.y8, F + 1, 0, s))) return rc;
-        hipLaunchKernelGGL(layered_sigma_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, R.y8,
-                           (int64_t)(F + 1), rows, sigma + r0);
-        if ((rc = nerf::check_launch("nerf_mlp_layered_forward: sigma"))) return rc;
-        // :116-119  cat([x[:, 1:], view_dir]) -- features first; rgb = sigmoid(fc_out(.))
-        if ((rc = linear_fwd(params, L, 9, R.y8 + 1, F + 1, F, v, E_d, E_d, rows, R.h9, L.H, 1, s))) return rc;
-        if ((rc = linear_fwd(params, L, 10, R.h9, L.H, L.H, nullptr, 0, 0, rows, rgb + 3 * r0, 3, 2, s))) return rc;
+        const int64_t MP = padded_rows(rows);
+        hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * D.Pp)), dim3(256), 0, s, pos + r0 * D.E_p, rows, MP,
+                           D.E_p, D.Pp, planes + (int64_t)D.r_pe() * MP);
+        hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * D.Dp)), dim3(256), 0, s, view_dir + r0 * D.E_d, rows, MP,
+                           D.E_d, D.Dp, planes + (int64_t)D.r_de() * MP);
+        if (int rc = nerf::check_launch("nerf_mlp_layered_forward: input planes")) return rc;
+        WideArgs a = {};
+        a.D = D; a.stream = reinterpret_cast<const char *>(fstream); a.consts = consts;
+        a.rec = planes; a.grad = nullptr; a.M = rows; a.MP = MP;
+        a.n_passes = fwd_num_passes(D); a.n_pairs = pa.n_pairs; a.inputs = 0;
+        a.sigma = sigma + r0; a.rgb = rgb + 3 * r0;
+        if (int rc = launch_program(false, a, s)) return rc;
     }
     return NERF_OK;
 }
@@ -371,64 +724,82 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
                                        const void *record, const float *g_sigma, const float *g_rgb,
                                        float *g_params, float *g_pos, float *g_view_dir, void *workspace,
                                        nerf_stream_t stream) {
+    (void)pos; (void)view_dir;   // the record holds the input planes
     nerf_net_t d;
     if (nerf::net_describe(net, d) < 0) return NERF_ERR_ARG;
     NERF_REQUIRE(M >= 0, "nerf_mlp_layered_backward: negative M");
     NERF_REQUIRE(g_params, "nerf_mlp_layered_backward: null g_params");
-    const Layout L(d);
+    const Dims D = make_dims(d);
     hipStream_t s = nerf::as_stream(stream);
     if (M == 0) {
-        if (hipMemsetAsync(g_params, 0, sizeof(float) * L.total, s) != hipSuccess)
+        if (hipMemsetAsync(g_params, 0, sizeof(float) * D.total, s) != hipSuccess)
             return nerf::check_launch("nerf_mlp_layered_backward: memset");
         return NERF_OK;
     }
-    NERF_REQUIRE(params && pos && view_dir && sigma && rgb && record && g_sigma && g_rgb && workspace,
+    NERF_REQUIRE(params && sigma && rgb && record && g_sigma && g_rgb && workspace,
                  "nerf_mlp_layered_backward: null pointer");
     NERF_REQUIRE(M < (int64_t)1 << 31, "nerf_mlp_layered_backward: more than 2^31 samples per call");
-    const int F = L.F, H = L.H, E_p = L.E_p, E_d = L.E_d, LD = F + 1;
-    const Record R(static_cast<float *>(const_cast<void *>(record)), M, L);
-    float *ga = static_cast<float *>(workspace);
-    float *gb = ga + align64(M * (int64_t)LD);
-    float *g9 = gb + align64(M * (int64_t)LD);
-    float *g10 = g9 + align64(M * (int64_t)H);
-    float *partial = g10 + align64(M * 3);
-    int rc;
-    // sigmoid / relu of the two heads; gb[:, 0] = d y8[:, 0]
-    hipLaunchKernelGGL(layered_heads_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, sigma, rgb, g_sigma,
-                       g_rgb, M, g10, gb, (int64_t)LD);
-    if ((rc = nerf::check_launch("nerf_mlp_layered_backward: heads"))) return rc;
-    // fc_out (:119)
-    if ((rc = linear_dw(g_params, L, 10, g10, 3, R.h9, H, M, 0, H, true, partial, s))) return rc;
-    if ((rc = linear_dx(params, L, 10, g10, 3, M, 0, H, g9, H, R.h9, H, 0, s))) return rc;           // . [h9 > 0]
-    // fc_9 on cat([y8[:, 1:], view_dir]) (:116-118)
-    if ((rc = linear_dw(g_params, L, 9, g9, H, R.y8 + 1, LD, M, 0, F, true, partial, s))) return rc;
-    if ((rc = linear_dw(g_params, L, 9, g9, H, view_dir, E_d, M, F, E_d, false, partial, s))) return rc;
-    if ((rc = linear_dx(params, L, 9, g9, H, M, 0, F, gb + 1, LD, nullptr, 0, 0, s))) return rc;     // d y8[:, 1:] (no ReLU)
-    if (g_view_dir && (rc = linear_dx(params, L, 9, g9, H, M, F, E_d, g_view_dir, E_d, nullptr, 0, 0, s))) return rc;
-    // fc_8 (:113): gb = d y8 (M, F+1)
-    if ((rc = linear_dw(g_params, L, 8, gb, LD, R.h[7], F, M, 0, F, true, partial, s))) return rc;
-    if ((rc = linear_dx(params, L, 8, gb, LD, M, 0, F, ga, LD, R.h[7], F, 0, s))) return rc;         // . [h7 > 0]
-    // fc_7, fc_6
-    float *cur = ga, *nxt = gb;
-    for (int l = 7; l >= 6; --l) {
-        if ((rc = linear_dw(g_params, L, l, cur, LD, R.h[l - 1], F, M, 0, F, true, partial, s))) return rc;
-        if ((rc = linear_dx(params, L, l, cur, LD, M, 0, F, nxt, LD, R.h[l - 1], F, 0, s))) return rc;
-        float *t = cur; cur = nxt; nxt = t;
+    const int inputs = (g_pos || g_view_dir) ? 1 : 0;
+    const int64_t MP = padded_rows(M);
+    const Sizes zr = sizes(D, M, false, 0), zw = sizes(D, M, true, 1);
+    const char *rbase = static_cast<const char *>(record);
+    const float *consts = reinterpret_cast<const float *>(rbase);
+    float *rec = reinterpret_cast<float *>(const_cast<char *>(rbase) + zr.consts + zr.fwd_stream);
+    char *wbase = static_cast<char *>(workspace);
+    float *dstream = reinterpret_cast<float *>(wbase);
+    float *grad = reinterpret_cast<float *>(wbase + zw.dx_stream);
+    float *thin = reinterpret_cast<float *>(wbase + zw.dx_stream + zw.planes);
+    const int64_t thin_bytes = align256b(4 * (int64_t)THIN_SLICES * (D.Fp + 3 * D.Hp + 4));
+    char *dw_scratch = wbase + zw.dx_stream + zw.planes + thin_bytes;
+
+    PackArgs pa; pa.D = D; pa.P = params; pa.dx = 1; pa.inputs = inputs; pa.n_pairs = stream_pairs(D, 1, inputs);
+    hipLaunchKernelGGL(layered_pack_stream, dim3((unsigned)(pa.n_pairs < 1024 ? pa.n_pairs : 1024)), dim3(256), 0, s, pa, dstream);
+    if (int rc = nerf::check_launch("nerf_mlp_layered_backward: pack")) return rc;
+    WideArgs a = {};
+    a.D = D; a.stream = reinterpret_cast<const char *>(dstream); a.consts = consts;
+    a.rec = rec; a.grad = grad; a.M = M; a.MP = MP;
+    a.n_passes = dx_num_passes(D, inputs); a.n_pairs = pa.n_pairs; a.inputs = inputs;
+    a.sigma_in = sigma; a.rgb_in = rgb; a.g_sigma = g_sigma; a.g_rgb = g_rgb;
+    if (int rc = launch_program(true, a, s)) return rc;
+    if (g_pos) hipLaunchKernelGGL(plane_to_rows_kernel, dim3(grid_for(M * D.E_p)), dim3(256), 0, s,
+                                  grad + (int64_t)D.g_gp() * MP, M, D.E_p, D.Pp, g_pos);
+    if (g_view_dir) hipLaunchKernelGGL(plane_to_rows_kernel, dim3(grid_for(M * D.E_d)), dim3(256), 0, s,
+                                       grad + (int64_t)D.g_gd() * MP, M, D.E_d, D.Dp, g_view_dir);
+    // thin rows
+    {
+        const int cols = D.Fp + 3 * D.Hp + 4;
+        int slices = (int)((M + 2047) / 2048);
+        if (slices > THIN_SLICES) slices = THIN_SLICES;
+        if (slices < 1) slices = 1;
+        hipLaunchKernelGGL(layered_thin_kernel, dim3((cols + 63) / 64, slices), dim3(64), 0, s, D, rec, grad, M, MP, thin);
+        hipLaunchKernelGGL(layered_thin_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, D, thin, slices, g_params);
+        if (int rc = nerf::check_launch("nerf_mlp_layered_backward: thin rows")) return rc;
     }
-    // fc_5 on cat([pos, h4]) (:108-110)
-    if ((rc = linear_dw(g_params, L, 5, cur, LD, pos, E_p, M, 0, E_p, false, partial, s))) return rc;
-    if ((rc = linear_dw(g_params, L, 5, cur, LD, R.h[4], F, M, E_p, F, true, partial, s))) return rc;
-    if (g_pos && (rc = linear_dx(params, L, 5, cur, LD, M, 0, E_p, g_pos, E_p, nullptr, 0, 0, s))) return rc;
-    if ((rc = linear_dx(params, L, 5, cur, LD, M, E_p, F, nxt, LD, R.h[4], F, 0, s))) return rc;     // . [h4 > 0]
-    { float *t = cur; cur = nxt; nxt = t; }
-    // fc_4 .. fc_1
-    for (int l = 4; l >= 1; --l) {
-        if ((rc = linear_dw(g_params, L, l, cur, LD, R.h[l - 1], F, M, 0, F, true, partial, s))) return rc;
-        if ((rc = linear_dx(params, L, l, cur, LD, M, 0, F, nxt, LD, R.h[l - 1], F, 0, s))) return rc;
-        float *t = cur; cur = nxt; nxt = t;
+    // dW / db: windows of <= 256 x 256 over (dY plane of the layer, its input plane(s))
+    std::vector<nerf::DwItem> items;
+    auto add = [&](int layer, const float *dy_plane, int n_w, int rows_total, int row0, const float *x_plane, int x_w,
+                   int cols_total, int col0, bool bias) {
+        for (int fa = 0; fa * 32 < n_w; fa += 8)
+            for (int fx = 0; fx * 32 < x_w; fx += 8) {
+                nerf::DwItem it;
+                it.a_plane = dy_plane; it.a_width = n_w; it.a_fb0 = fa; it.a_blocks = n_w / 32 - fa < 8 ? n_w / 32 - fa : 8;
+                it.x_plane = x_plane; it.x_width = x_w; it.x_fb0 = fx; it.x_blocks = x_w / 32 - fx < 8 ? x_w / 32 - fx : 8;
+                it.ld = D.in[layer];
+                it.w_dst = g_params + D.w[layer] + (int64_t)(row0 + fa * 32) * D.in[layer] + col0 + fx * 32;
+                it.rows_valid = rows_total - fa * 32 < 256 ? rows_total - fa * 32 : 256;
+                it.cols_valid = cols_total - fx * 32 < 256 ? cols_total - fx * 32 : 256;
+                it.b_dst = (bias && fx == 0) ? g_params + D.b[layer] + row0 + fa * 32 : nullptr;
+                if (it.rows_valid > 0 && it.cols_valid > 0) items.push_back(it);
+            }
+    };
+    auto gp = [&](int off) { return grad + (int64_t)off * MP; };
+    auto rp = [&](int off) { return rec + (int64_t)off * MP; };
+    add(0, gp(D.g_dy(0)), D.Fp, D.F, 0, rp(D.r_pe()), D.Pp, D.E_p, 0, true);
+    for (int l = 1; l <= 8; ++l) {
+        if (l == 5) add(5, gp(D.g_dy(5)), D.Fp, D.F, 0, rp(D.r_pe()), D.Pp, D.E_p, 0, false);
+        add(l, gp(D.g_dy(l)), D.Fp, D.F, l == 8 ? 1 : 0, rp(D.r_h(l - 1)), D.Fp, D.F, l == 5 ? D.E_p : 0, true);
     }
-    // fc_in (:102); autograd ADDS its contribution to `pos` to the skip connection's
-    if ((rc = linear_dw(g_params, L, 0, cur, LD, pos, E_p, M, 0, E_p, true, partial, s))) return rc;
-    if (g_pos && (rc = linear_dx(params, L, 0, cur, LD, M, 0, E_p, g_pos, E_p, nullptr, 0, 1, s))) return rc;
-    return NERF_OK;
+    add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_h(8)), D.Fp, D.F, 0, true);
+    add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_de()), D.Dp, D.E_d, D.F, false);
+    return nerf::run_dw_items(items, M, dw_scratch, nerf::dw_items_scratch_bytes((int)items.size()) + 65536, s);
 }
