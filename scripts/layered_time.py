@@ -13,7 +13,11 @@ def t(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-for (e_p, e_d, F) in ((63, 27, 256), (63, 27, 128), (75, 39, 64), (63, 27, 512)):
+NETS = ((63, 27, 256), (63, 27, 128), (75, 39, 64), (63, 27, 512))
+if len(sys.argv) > 2:   # e.g. "128,512": feat_dims to run (profiling passes)
+    NETS = tuple(n for n in NETS if str(n[2]) in sys.argv[2].split(","))
+PEAK = 157.3
+for (e_p, e_d, F) in NETS:
     net = ops.Net.dims_only(e_p, e_d, F)
     flat = torch.from_numpy(synth.nerf_flat_params(seed=1, pos_dim=e_p, view_dir_dim=e_d, feat_dim=F)).cuda()
     pe, de = torch.randn(M, e_p, device="cuda"), torch.randn(M, e_d, device="cuda")
@@ -23,7 +27,9 @@ for (e_p, e_d, F) in ((63, 27, 256), (63, 27, 128), (75, 39, 64), (63, 27, 512))
     fwd = t(lambda: ops.mlp_layered_forward(flat, pe, de, net))
     sigma, rgb, rec = ops.mlp_layered_forward(flat, pe, de, net, record=True)
     bwd = t(lambda: ops.mlp_layered_backward(flat, pe, de, net, sigma, rgb, rec, gs, gc))
-    line = f"NeRF({e_p},{e_d},{F}) M={M}: layered fwd {fwd:7.2f} ms = {2*mac*M/fwd/1e9:6.1f} TFLOP/s   bwd {bwd:7.2f} ms = {4*mac*M/bwd/1e9:6.1f} TFLOP/s"
+    rfwd = t(lambda: ops.mlp_layered_forward(flat, pe, de, net, record=True))
+    line = (f"NeRF({e_p},{e_d},{F}) M={M}: layered fwd {fwd:7.2f} ms = {2*mac*M/fwd/1e9:6.1f} TFLOP/s ({2*mac*M/fwd/1e9/PEAK:.2f})   "
+            f"record fwd {rfwd:7.2f} ms ({2*mac*M/rfwd/1e9/PEAK:.2f})   bwd {bwd:7.2f} ms = {4*mac*M/bwd/1e9:6.1f} TFLOP/s ({4*mac*M/bwd/1e9/PEAK:.2f})")
     if net.fused:
         packed = ops.mlp_pack(flat, net)
         f2 = t(lambda: ops.mlp_forward(packed, pe, de, True, net=net))

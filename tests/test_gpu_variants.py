@@ -175,6 +175,42 @@ def test_full_tensor_vs_oracle(oracle, golden, tag, M):
         assert_grads_match_given_masks(got.cpu().numpy(), want_g, split, "fused ")
 
 
+@pytest.mark.parametrize("dims,M", [((21, 15, 128), 700), ((63, 27, 128), 2049), ((75, 27, 100), 513), ((96, 32, 128), 256),
+                                    ((63, 27, 512), 300), ((40, 40, 160), 333), ((63, 27, 96), 129)])
+def test_layered_family_any_widths_vs_oracle(oracle, dims, M):
+    """Widths the fixtures do not hold, every element against the CPU oracle under the kernel's own ReLU decisions:
+    the register-resident narrow kernels (feat_dim 97..128, pos_dim <= 96 -> one, two and three position blocks,
+    ragged feat_dim 100) and the general plane-parked kernel (feat_dim 512: two passes per layer; 160: a ragged
+    pass; view_dir_dim 40: two direction blocks), forward, parameter gradients and input gradients."""
+    from helpers import assert_grads_match_given_masks, layered_masks
+    e_p, e_d, feat = dims
+    rng = np.random.RandomState(M + feat)
+    pe = rng.uniform(-1, 1, (M, e_p)).astype(np.float32)
+    de = rng.uniform(-1, 1, (M, e_d)).astype(np.float32)
+    gs, gc = rng.standard_normal(M).astype(np.float32), rng.standard_normal((M, 3)).astype(np.float32)
+    flat = synth.nerf_flat_params(seed=21, pos_dim=e_p, view_dir_dim=e_d, feat_dim=feat, sigma_bias=0.3, sigma_gain=6.0)
+    spec = ops.Net.dims_only(*dims)
+    assert not spec.fused
+    fp = dev(flat)
+    want_s, want_c = oracle.mlp_forward(flat, pe, de, F=feat)
+    s0, c0 = ops.mlp_layered_forward(fp, dev(pe), dev(de), spec)                      # inference entry: nothing recorded
+    sigma, rgb, rec = ops.mlp_layered_forward(fp, dev(pe), dev(de), spec, record=True)
+    assert torch.equal(s0, sigma) and torch.equal(c0, rgb)
+    np.testing.assert_allclose(sigma.cpu().numpy(), want_s, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(rgb.cpu().numpy(), want_c, rtol=0, atol=1e-5)
+    _, _, _, own = oracle.mlp_backward_ex(flat, pe, de, gs, gc, F=feat, want_inputs=False, want_masks=True)
+    masks = layered_masks(rec, sigma, M, spec)
+    assert (masks != own).mean() < 1e-5, f"{(masks != own).sum()} ReLU decisions differ from the oracle's"
+    want_g, want_gp, want_gd, _ = oracle.mlp_backward_ex(flat, pe, de, gs, gc, F=feat, force_masks=masks)
+    got, g_pos, g_dir = ops.mlp_layered_backward(fp, dev(pe), dev(de), spec, sigma, rgb, rec, dev(gs), dev(gc),
+                                                 want_pos=True, want_dir=True)
+    plain, _, _ = ops.mlp_layered_backward(fp, dev(pe), dev(de), spec, sigma, rgb, rec, dev(gs), dev(gc))
+    assert torch.equal(plain, got)
+    assert_grads_match_given_masks(got.cpu().numpy(), want_g, lambda v: synth.split_flat_params(v, *dims), f"{dims} ")
+    for a, b in ((g_pos.cpu().numpy(), want_gp), (g_dir.cpu().numpy(), want_gd)):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * np.abs(b).max())
+
+
 def test_layered_gradients_are_deterministic():
     """No atomics: the sliced sample-axis reductions add up in a fixed order."""
     dims = (63, 27, 128)

@@ -275,6 +275,52 @@ __device__ __forceinline__ void mma_slots(f32x16 *acc, const f32x16 *b, const ch
     }
 }
 
+// Two SAMPLE blocks per wavefront (mlp_layered.hip, narrow networks: 64 samples x 128 features fill the registers that
+// 32 samples x 256 features fill in the wide kernels): every A fragment feeds 8 MFMAs instead of 4 -- half the LDS
+// reads and half the weight stream per MFMA.  Slot-major chunk as in mma_slots, slot = kb * STRIDE + fb; the k-blocks
+// multiplied are kb = 0 .. NKB-1, the operands of k-block kb are bsel(0, kb) / bsel(1, kb) (references to f32x16).
+template <int NFB, int NKB, int STRIDE, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false, class BSel>
+__device__ __forceinline__ void mma_slots2(f32x16 *acc0, f32x16 *acc1, BSel bsel, const char *chunk, const int (&offq)[4],
+                                           const Pipe *pipe = nullptr) {
+    static_assert(NFB <= STRIDE && STRIDE * NKB <= 8, "a chunk holds eight slots");
+    constexpr int GROUPS = 4 * NFB * NKB;
+    const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)chunk;
+    unsigned addr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) addr[q] = base + (unsigned)offq[q];
+    f32x4 abuf[2];
+    abuf[0] = lds_read_fragment(addr[0], 0);
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        const int kb = g / (4 * NFB), q = (g / NFB) % 4, fb = g % NFB;
+        lds_fragments_ready();
+        if (g + 1 < GROUPS) {
+            const int g1 = g + 1, kb1 = g1 / (4 * NFB), q1 = (g1 / NFB) % 4, fb1 = g1 % NFB;
+            abuf[g1 & 1] = lds_read_fragment(addr[q1], (kb1 * STRIDE + fb1) * 4096);
+        }
+        const f32x4 a = abuf[g & 1];
+        const f32x16 &b0 = bsel(0, kb), &b1 = bsel(1, kb);
+        if (FRESH && kb == 0 && q == 0) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc0[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0[4 * q + 0], zero, 0, 0, 0);
+            acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[4 * q + 0], zero, 0, 0, 0);
+        } else {
+            acc0[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0[4 * q + 0], acc0[fb], 0, 0, 0);
+            acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[4 * q + 0], acc1[fb], 0, 0, 0);
+        }
+        acc0[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0[4 * q + 1], acc0[fb], 0, 0, 0);
+        acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1[4 * q + 1], acc1[fb], 0, 0, 0);
+        if (N_PIECES > 0) {   // the next pair's DMA pieces, spread evenly over this chunk's groups
+#pragma unroll
+            for (int pp = g * N_PIECES / GROUPS; pp < (g + 1) * N_PIECES / GROUPS; ++pp) pipe->issue_piece(FIRST_PIECE + pp);
+        }
+        acc0[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0[4 * q + 2], acc0[fb], 0, 0, 0);
+        acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1[4 * q + 2], acc1[fb], 0, 0, 0);
+        acc0[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0[4 * q + 3], acc0[fb], 0, 0, 0);
+        acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1[4 * q + 3], acc1[fb], 0, 0, 0);
+    }
+}
+
 // One pipeline step: both chunks of the acquired pair.  The next pair's 16 DMA pieces are all
 // issued during the FIRST chunk, so the youngest of them still has a whole chunk of MFMAs
 // (8 k cycles) to land before the next acquire waits for it.
@@ -365,17 +411,18 @@ __device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, i
             // without them: in the pre-encoded forward, where nothing else sits between the two, one store in ~60
             // went to the previous plane's address -- stale PE / DE planes, 5 % gradient error, run to run different;
             // scripts/audit_asm_loads.py now checks every asm VMEM instruction for this).
-            if (fb == 0 && q == 0)
-                asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3"
-                             :
-                             : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024)
-                             : "memory");
-            else
-                asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3"
-                             :
-                             : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024)
-                             : "memory");
-            if (PAD) asm volatile("s_nop 1");
+            // (PAD: the wait states ride in the SAME asm statement -- a separate one may be scheduled away from its store)
+            if (fb == 0 && q == 0) {
+                if (PAD) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
+                                      : : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024) : "memory");
+                else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3"
+                                  : : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024) : "memory");
+            } else {
+                if (PAD) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
+                                      : : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3"
+                                  : : "v"(unit16 ^ (32u * q)), "v"(v), "s"(base), "n"(q * 1024) : "memory");
+            }
         }
     }
 }

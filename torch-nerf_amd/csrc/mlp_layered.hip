@@ -45,6 +45,8 @@ namespace {
 using namespace mlp;
 
 constexpr int ROUND32(int x) { return (x + 31) & ~31; }
+// rows of every plane of this family: whole 256-sample tiles (the narrow kernels walk 64 samples per wavefront)
+__host__ __device__ constexpr int64_t lrows(int64_t M) { return (M + 255) / 256 * 256; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // geometry
@@ -186,8 +188,9 @@ __host__ __device__ inline Pass dx_pass(const Dims &D, int inputs, int idx) {
         if (st == 0) { P.dst_off = D.g_dy(8); P.dst_w = D.Fp; P.col00 = 0; P.cols_valid0 = D.F; }
         else         { P.dst_off = D.g_gd(); P.dst_w = D.Dp; P.col00 = D.F; P.cols_valid0 = D.E_d; }
     } else if (st == 10) {  // g_pos: two sources, two layers
-        P.kb0 = D.Fp / 32; P.src_off0 = D.g_dy(5); P.src_w0 = D.Fp; P.layer0 = 5;
-        P.kb1 = D.Fp / 32; P.src_off1 = D.g_dy(0); P.src_w1 = D.Fp; P.layer1 = 0;
+        // (dY0 first: the narrow kernels still hold it in registers when they get here)
+        P.kb0 = D.Fp / 32; P.src_off0 = D.g_dy(0); P.src_w0 = D.Fp; P.layer0 = 0;
+        P.kb1 = D.Fp / 32; P.src_off1 = D.g_dy(5); P.src_w1 = D.Fp; P.layer1 = 5;
         P.row0 = 0; P.rows_valid = D.F; P.col00 = P.col01 = 0; P.cols_valid0 = P.cols_valid1 = D.E_p;
         P.dst_off = D.g_gp(); P.dst_w = D.Pp;
     } else {                // stage st = 2..9: layer l = 10 - st (8 .. 1): dY(l-1) from dY(l)
@@ -569,39 +572,482 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// narrow networks (feat_dim 97..128, view_dir_dim <= 32, pos_dim <= 96, e.g. NeRF(63, 27, 128)): register-resident
+// ---------------------------------------------------------------------------------------------------------------
+// 128 features x 64 samples per wavefront fill the registers that 256 x 32 fill in the fused family: the D fragment
+// of a layer is the B fragment of the next again, nothing is parked -- planes are written only for a backward that
+// will read them (RECORD) -- and every A fragment feeds two sample blocks (mma_slots2).  Same streams, same planes,
+// same dW path as the general kernel above, whose pass programs these kernels walk with everything unrolled:
+//   forward   fc_in 1 pair | fc_1..4 1 each | fc_5 2 | fc_6..8 1 each | fc_9 1           (PB = pos blocks, 1..3)
+//   reverse   fc_9^T 1 | [g_view_dir 1] | fc_8^T .. fc_1^T 1 each | [g_pos 1 (PB <= 2) or 2 (PB = 3)]
+constexpr int NARROW_LDS = RING_SLOTS * CHUNK_BYTES + 8192;   // ring + the constant block (<= 2048 floats)
+
+__host__ __device__ inline bool narrow_ok(const Dims &D) { return D.Fp == 128 && D.Hp == 64 && D.Dp == 32 && D.Pp <= 96; }
+
+struct NCtx {
+    const char *lds;
+    const float *cb;
+    int offq[4];
+    int i, h;
+};
+
+// this lane's 16 registers of block `blk` of a 32-sample tile (the lane's own slots, as save_plane stores them)
+__device__ __forceinline__ f32x16 load_block(const float *tile, int blk, int i, int h) {
+    f32x16 x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + (blk * 4 + q) * 256 + 4 * ((2 * i + h) ^ (2 * q)));
+        x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+    return x;
+}
+
+template <int NB>
+__device__ __forceinline__ void bias_init(f32x16 *acc0, f32x16 *acc1, const float *bias, int h) {
+#pragma unroll
+    for (int fb = 0; fb < NB; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(bias + 32 * fb + 8 * q + 4 * h);
+            acc0[fb][4 * q + 0] = v.x; acc0[fb][4 * q + 1] = v.y; acc0[fb][4 * q + 2] = v.z; acc0[fb][4 * q + 3] = v.w;
+            acc1[fb][4 * q + 0] = v.x; acc1[fb][4 * q + 1] = v.y; acc1[fb][4 * q + 2] = v.z; acc1[fb][4 * q + 3] = v.w;
+        }
+}
+
+template <int PB, bool RECORD>
+__global__ __launch_bounds__(256, 1) void narrow_forward_kernel(const WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    float *cb = reinterpret_cast<float *>(lds + RING_SLOTS * CHUNK_BYTES);
+    for (int e = tid; e < a.D.c_floats() / 4; e += 256)
+        reinterpret_cast<f32x4 *>(cb)[e] = reinterpret_cast<const f32x4 *>(a.consts)[e];
+    int offq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) offq[q] = chunk_slot_offset(i, 2 * q + h);
+    Pipe pipe;
+    pipe.src_wave = a.stream + wave * 8192;
+    pipe.lane_off = (unsigned)lane * 16u;
+    pipe.lds_wave = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 8192u;
+    pipe.issued = 0; pipe.issue_pos = 0; pipe.consumed = 0;
+    pipe.n_pairs = a.n_pairs; pipe.skip_mask = 0;
+    __syncthreads();
+    pipe.issue();
+    const Dims &D = a.D;
+    const int64_t MP = a.MP;
+    auto plane = [&](int off) { return a.rec + (int64_t)off * MP; };
+
+    for (int64_t tile = blockIdx.x; tile < MP / 256; tile += gridDim.x) {
+        const int64_t row0 = tile * 256 + wave * 64;
+        const int64_t m[2] = {row0 + i, row0 + 32 + i};
+        f32x16 pe[2][PB], de[2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            const float *pt = plane(D.r_pe()) + (row0 + 32 * sb) * D.Pp;
+#pragma unroll
+            for (int b = 0; b < PB; ++b) pe[sb][b] = load_block(pt, b, i, h);
+            de[sb] = load_block(plane(D.r_de()) + (row0 + 32 * sb) * 32, 0, i, h);
+        }
+        f32x16 acc[2][4], act[2][4];
+
+        // ---- fc_in (nerf.py:102)
+        {
+            const char *w = lds + pipe.acquire();
+            bias_init<4>(acc[0], acc[1], cb + D.c_bias(0), h);
+            auto P = [&](int sb, int kb) -> const f32x16 & { return pe[sb][kb]; };
+            auto P2 = [&](int sb, int kb) -> const f32x16 & { return pe[sb][PB - 1]; };
+            if constexpr (PB == 1) mma_slots2<4, 1, 4, 0, 16>(acc[0], acc[1], P, w, offq, &pipe);
+            else mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], P, w, offq, &pipe);
+            if constexpr (PB == 3) mma_slots2<4, 1, 4>(acc[0], acc[1], P2, w + CHUNK_BYTES, offq);
+            pipe.issue_done();
+        }
+        // ---- fc_1 .. fc_8 (:103-113); skip connection at fc_5, pos FIRST (:108)
+        float sig[2] = {0.0f, 0.0f};
+        for (int l = 1; l <= 8; ++l) {
+            const char *w = lds + pipe.acquire();
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) act[sb][fb][r] = relu1(acc[sb][fb][r]);
+            if (RECORD) {
+                save_plane<4, true>(plane(D.r_h(l - 1)), 128, m[0], h, act[0]);
+                save_plane<4, true>(plane(D.r_h(l - 1)), 128, m[1], h, act[1]);
+            }
+            if (l == 8) {   // density row of fc_8
+                sig[0] = half_dot<4>(cb + D.c_w8row(), act[0], h);
+                sig[1] = half_dot<4>(cb + D.c_w8row(), act[1], h);
+            }
+            bias_init<4>(acc[0], acc[1], cb + D.c_bias(l), h);
+            auto A0 = [&](int sb, int kb) -> const f32x16 & { return act[sb][kb]; };
+            auto A1 = [&](int sb, int kb) -> const f32x16 & { return act[sb][1 + kb]; };
+            auto A2 = [&](int sb, int kb) -> const f32x16 & { return act[sb][2 + kb]; };
+            auto A3 = [&](int sb, int kb) -> const f32x16 & { return act[sb][3]; };
+            if (l == 5) {   // k-blocks: pos blocks, then h4's four; two per chunk
+                // (the encoded position comes back from its plane -- L2-hot -- instead of living in 32 PB registers
+                // through fc_1..fc_4: with three blocks that alone spills)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) pe[sb][b] = load_block(plane(D.r_pe()) + (row0 + 32 * sb) * D.Pp, b, i, h);
+                auto P = [&](int sb, int kb) -> const f32x16 & { return pe[sb][kb]; };
+                if constexpr (PB == 1) {
+                    auto PA = [&](int sb, int kb) -> const f32x16 & { return kb == 0 ? pe[sb][0] : act[sb][0]; };
+                    mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], PA, w, offq, &pipe);
+                    mma_slots2<4, 2, 4>(acc[0], acc[1], A1, w + CHUNK_BYTES, offq);
+                    pipe.issue_done();
+                    w = lds + pipe.acquire();
+                    mma_slots2<4, 1, 4, 0, 16>(acc[0], acc[1], A3, w, offq, &pipe);
+                } else if constexpr (PB == 2) {
+                    mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], P, w, offq, &pipe);
+                    mma_slots2<4, 2, 4>(acc[0], acc[1], A0, w + CHUNK_BYTES, offq);
+                    pipe.issue_done();
+                    w = lds + pipe.acquire();
+                    mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], A2, w, offq, &pipe);
+                } else {
+                    auto PA = [&](int sb, int kb) -> const f32x16 & { return kb == 0 ? pe[sb][PB - 1] : act[sb][0]; };
+                    mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], P, w, offq, &pipe);
+                    mma_slots2<4, 2, 4>(acc[0], acc[1], PA, w + CHUNK_BYTES, offq);
+                    pipe.issue_done();
+                    w = lds + pipe.acquire();
+                    mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], A1, w, offq, &pipe);
+                    mma_slots2<4, 1, 4>(acc[0], acc[1], A3, w + CHUNK_BYTES, offq);
+                }
+                pipe.issue_done();
+            } else {
+                mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], A0, w, offq, &pipe);
+                mma_slots2<4, 2, 4>(acc[0], acc[1], A2, w + CHUNK_BYTES, offq);
+                pipe.issue_done();
+            }
+        }
+        // ---- fc_9 on cat([x[:, 1:], view_dir]) (:116-118); fc_8 has no ReLU (:113)
+        f32x16 a9[2][2];
+        {
+            const char *w = lds + pipe.acquire();
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb) act[sb][fb] = acc[sb][fb];
+            if (RECORD) {
+                save_plane<4, true>(plane(D.r_h(8)), 128, m[0], h, act[0]);
+                save_plane<4, true>(plane(D.r_h(8)), 128, m[1], h, act[1]);
+            }
+            bias_init<2>(a9[0], a9[1], cb + D.c_bias(9), h);
+            auto Y = [&](int sb, int kb) -> const f32x16 & { return act[sb][kb]; };
+            auto V = [&](int sb, int kb) -> const f32x16 & { return de[sb]; };
+            mma_slots2<2, 4, 2, 0, 16>(a9[0], a9[1], Y, w, offq, &pipe);
+            mma_slots2<2, 1, 2>(a9[0], a9[1], V, w + CHUNK_BYTES, offq);
+            pipe.issue_done();
+        }
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a9[sb][fb][r] = relu1(a9[sb][fb][r]);
+            if (RECORD) save_plane<2, true>(plane(D.r_h9()), 64, m[sb], h, a9[sb]);
+            float s = sig[sb] + __shfl_xor(sig[sb], 32, WAVE);
+            s = fmaxf(s + cb[D.c_scal()], 0.0f);                      // relu(x[:, 0]) (:115)
+            float y[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {                           // sigmoid(fc_out(h9)) (:119)
+                float p = half_dot<2>(cb + D.c_wout() + ch * 64, a9[sb], h);
+                p += __shfl_xor(p, 32, WAVE);
+                y[ch] = 1.0f / (1.0f + expf(-(p + cb[D.c_scal() + 1 + ch])));
+            }
+            if (m[sb] < a.M && h == 0) {
+                a.sigma[m[sb]] = s;
+                a.rgb[3 * m[sb] + 0] = y[0]; a.rgb[3 * m[sb] + 1] = y[1]; a.rgb[3 * m[sb] + 2] = y[2];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// v where the forward activation was positive, else +0
+__device__ __forceinline__ f32x16 masked_by(const f32x16 &v, const f32x16 &act) {
+    f32x16 x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = act[r] > 0.0f ? v[r] : 0.0f;
+    return x;
+}
+
+template <int PB, bool IG>
+__global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    float *cb = reinterpret_cast<float *>(lds + RING_SLOTS * CHUNK_BYTES);
+    for (int e = tid; e < a.D.c_floats() / 4; e += 256)
+        reinterpret_cast<f32x4 *>(cb)[e] = reinterpret_cast<const f32x4 *>(a.consts)[e];
+    int offq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) offq[q] = chunk_slot_offset(i, 2 * q + h);
+    Pipe pipe;
+    pipe.src_wave = a.stream + wave * 8192;
+    pipe.lane_off = (unsigned)lane * 16u;
+    pipe.lds_wave = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 8192u;
+    pipe.issued = 0; pipe.issue_pos = 0; pipe.consumed = 0;
+    pipe.n_pairs = a.n_pairs; pipe.skip_mask = 0;
+    __syncthreads();
+    pipe.issue();
+    const Dims &D = a.D;
+    const int64_t MP = a.MP;
+    auto rplane = [&](int off) { return a.rec + (int64_t)off * MP; };
+    auto gplane = [&](int off) { return a.grad + (int64_t)off * MP; };
+
+    for (int64_t tile = blockIdx.x; tile < MP / 256; tile += gridDim.x) {
+        const int64_t row0 = tile * 256 + wave * 64;
+        const int64_t m[2] = {row0 + i, row0 + 32 + i};
+        // ---- heads (nerf.py:115, :119) and dY9 = (W_out^T d y10) . [h9 > 0]
+        float dsig[2];
+        f32x16 d9[2][2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            const bool valid = m[sb] < a.M;
+            const int64_t mc = valid ? m[sb] : a.M - 1;
+            float gy[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float y = a.rgb_in[3 * mc + ch];
+                gy[ch] = valid ? a.g_rgb[3 * mc + ch] * y * (1.0f - y) : 0.0f;
+            }
+            dsig[sb] = (valid && a.sigma_in[mc] > 0.0f) ? a.g_sigma[mc] : 0.0f;
+            if (h == 0) {
+                const f32x4 g4 = {gy[0], gy[1], gy[2], 0.0f};
+                *reinterpret_cast<f32x4 *>(gplane(D.g_gy()) + 4 * m[sb]) = g4;
+                gplane(D.g_dsig())[m[sb]] = dsig[sb];
+            }
+            const float *h9t = rplane(D.r_h9()) + (row0 + 32 * sb) * 64;
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                const f32x16 hv = load_block(h9t, fb, i, h);
+                f32x16 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k0 = 32 * fb + 8 * q + 4 * h;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + k0);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + 64 + k0);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + 128 + k0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[4 * q + j] = fmaf(w2[j], gy[2], fmaf(w1[j], gy[1], w0[j] * gy[0]));
+                }
+                d9[sb][fb] = masked_by(v, hv);
+            }
+            save_plane<2, true>(gplane(D.g_dy9()), 64, m[sb], h, d9[sb]);
+        }
+        f32x16 acc[2][4], act[2][4], mk[2][4];
+        auto D9 = [&](int sb, int kb) -> const f32x16 & { return d9[sb][kb]; };
+        // ---- d y8[1:] = W9[:, :F]^T dY9
+        {
+            const char *w = lds + pipe.acquire();
+            mma_slots2<4, 2, 4, 0, 16, true>(acc[0], acc[1], D9, w, offq, &pipe);
+            pipe.issue_done();
+        }
+        if (IG) {   // g_view_dir = W9[:, F:]^T dY9 (nerf.py:116)
+            const char *w = lds + pipe.acquire();
+            f32x16 gd[2];
+            mma_slots2<1, 2, 2, 0, 16, true>(&gd[0], &gd[1], D9, w, offq, &pipe);
+            pipe.issue_done();
+            save_plane<1, true>(gplane(D.g_gd()), 32, m[0], h, &gd[0]);
+            save_plane<1, true>(gplane(D.g_gd()), 32, m[1], h, &gd[1]);
+        }
+        // ReLU masks = the forward activations, fetched one stage ahead of the seam that applies them
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) mk[sb][fb] = load_block(rplane(D.r_h(7)) + (row0 + 32 * sb) * 128, fb, i, h);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- l = 8 .. 1: dY(l-1) = (W_l^T dY(l)) . [h(l-1) > 0]; the accumulators entering stage l hold dY(l) unmasked
+        for (int l = 8; l >= 1; --l) {
+            const char *w = lds + pipe.acquire();
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb) act[sb][fb] = l == 8 ? acc[sb][fb] : masked_by(acc[sb][fb], mk[sb][fb]);
+            if (l < 8) {   // masks of the next seam: h(l-1)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int fb = 0; fb < 4; ++fb)
+                        mk[sb][fb] = load_block(rplane(D.r_h(l - 1)) + (row0 + 32 * sb) * 128, fb, i, h);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            save_plane<4, true>(gplane(D.g_dy(l)), 128, m[0], h, act[0]);
+            save_plane<4, true>(gplane(D.g_dy(l)), 128, m[1], h, act[1]);
+            auto A0 = [&](int sb, int kb) -> const f32x16 & { return act[sb][kb]; };
+            auto A2 = [&](int sb, int kb) -> const f32x16 & { return act[sb][2 + kb]; };
+            if (l == 8) {   // + W8[0, :] dsigma' (the density row)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4 *>(cb + D.c_w8row() + 32 * fb + 8 * q + 4 * h);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[sb][fb][4 * q + j] = wv[j] * dsig[sb];
+                        }
+                mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], A0, w, offq, &pipe);
+            } else {
+                mma_slots2<4, 2, 4, 0, 16, true>(acc[0], acc[1], A0, w, offq, &pipe);
+            }
+            mma_slots2<4, 2, 4>(acc[0], acc[1], A2, w + CHUNK_BYTES, offq);
+            pipe.issue_done();
+        }
+        // ---- dY0
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) act[sb][fb] = masked_by(acc[sb][fb], mk[sb][fb]);
+            save_plane<4, true>(gplane(D.g_dy(0)), 128, m[sb], h, act[sb]);
+        }
+        if (IG) {   // g_pos = W_in^T dY0 + W5[:, :E_p]^T dY5 (nerf.py:102, :108); dY5 back from its plane
+            auto A0 = [&](int sb, int kb) -> const f32x16 & { return act[sb][kb]; };
+            auto A2 = [&](int sb, int kb) -> const f32x16 & { return act[sb][2 + kb]; };
+            f32x16 gp[2][PB];
+            auto reload = [&]() {
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int fb = 0; fb < 4; ++fb)
+                        act[sb][fb] = load_block(gplane(D.g_dy(5)) + (row0 + 32 * sb) * 128, fb, i, h);
+            };
+            const char *w = lds + pipe.acquire();
+            if constexpr (PB <= 2) {   // pass of 2 blocks: four k-blocks per chunk
+                mma_slots2<PB, 4, 2, 0, 16, true>(gp[0], gp[1], A0, w, offq, &pipe);
+                reload();
+                mma_slots2<PB, 4, 2>(gp[0], gp[1], A0, w + CHUNK_BYTES, offq);
+                pipe.issue_done();
+            } else {         // pass of 4 blocks: two k-blocks per chunk, two pairs
+                mma_slots2<PB, 2, 4, 0, 16, true>(gp[0], gp[1], A0, w, offq, &pipe);
+                mma_slots2<PB, 2, 4>(gp[0], gp[1], A2, w + CHUNK_BYTES, offq);
+                pipe.issue_done();
+                reload();
+                w = lds + pipe.acquire();
+                mma_slots2<PB, 2, 4, 0, 16>(gp[0], gp[1], A0, w, offq, &pipe);
+                mma_slots2<PB, 2, 4>(gp[0], gp[1], A2, w + CHUNK_BYTES, offq);
+                pipe.issue_done();
+            }
+            save_plane<PB, true>(gplane(D.g_gp()), 32 * PB, m[0], h, gp[0]);
+            save_plane<PB, true>(gplane(D.g_gp()), 32 * PB, m[1], h, gp[1]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int PB>
+int launch_narrow_pb(bool dx, bool flag, const WideArgs &a, hipStream_t s) {
+    const void *kern = dx ? (flag ? reinterpret_cast<const void *>(narrow_dx_kernel<PB, true>)
+                               : reinterpret_cast<const void *>(narrow_dx_kernel<PB, false>))
+                          : (flag ? reinterpret_cast<const void *>(narrow_forward_kernel<PB, true>)
+                               : reinterpret_cast<const void *>(narrow_forward_kernel<PB, false>));
+    static nerf::DeviceMask configured[4] = {{0}, {0}, {0}, {0}};
+    if (int rc = nerf::ensure_dynamic_lds(kern, NARROW_LDS, configured[2 * dx + flag], "nerf_mlp_layered: LDS attribute (narrow)"))
+        return rc;
+    const int64_t ntiles = a.MP / 256;
+    const int cus = nerf::device_cus();
+    const dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));
+    if (dx) {
+        if (flag) hipLaunchKernelGGL((narrow_dx_kernel<PB, true>), grid, dim3(256), NARROW_LDS, s, a);
+        else hipLaunchKernelGGL((narrow_dx_kernel<PB, false>), grid, dim3(256), NARROW_LDS, s, a);
+    } else {
+        if (flag) hipLaunchKernelGGL((narrow_forward_kernel<PB, true>), grid, dim3(256), NARROW_LDS, s, a);
+        else hipLaunchKernelGGL((narrow_forward_kernel<PB, false>), grid, dim3(256), NARROW_LDS, s, a);
+    }
+    return nerf::check_launch(dx ? "nerf_mlp_layered_backward: reverse chain (narrow)" : "nerf_mlp_layered_forward (narrow)");
+}
+
+// flag: forward -> record the planes; reverse chain -> input gradients
+int launch_narrow(bool dx, bool flag, const WideArgs &a, hipStream_t s) {
+    const int pb = a.D.Pp / 32;
+    return pb == 1 ? launch_narrow_pb<1>(dx, flag, a, s) : pb == 2 ? launch_narrow_pb<2>(dx, flag, a, s)
+                                                                   : launch_narrow_pb<3>(dx, flag, a, s);
+}
+
 // thin reductions of the reverse pass (vector ALU, HBM-bound: one more read of the h7 and h9 planes):
 //   fc_8.weight[0, k] = sum_m dsig[m] h7[m][k],  fc_out.weight[c][k] = sum_m gy[m][c] h9[m][k],
 //   fc_8.bias[0] = sum dsig,  fc_out.bias[c] = sum gy[.][c]
-// grid.y slices of the sample axis write partials; a second kernel adds them in order (deterministic).
-constexpr int THIN_SLICES = 64;
-__global__ void layered_thin_kernel(const Dims D, const float *__restrict__ rec, const float *__restrict__ grad,
-                                    int64_t M, int64_t MP, float *__restrict__ partial) {
+// One wavefront per (32-feature block, slice of the sample axis): a 32-sample tile of the block is 4 KiB = four
+// coalesced 16-byte loads per lane; lane (i, h) keeps the partial sums of sample i of every tile in double, the 32
+// lanes of a half are added up once at the end.  Slices are summed in a fixed order by the second kernel: no atomics.
+constexpr int THIN_SLICES = 256;
+__global__ __launch_bounds__(64) void layered_thin_kernel(const Dims D, const float *__restrict__ rec,
+                                                          const float *__restrict__ grad, int64_t MP, int slices,
+                                                          double *__restrict__ partial) {
     const int cols = D.Fp + 3 * D.Hp + 4;
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= cols) return;
-    const int64_t per = (M + gridDim.y - 1) / gridDim.y, m0 = blockIdx.y * per, m1 = m0 + per < M ? m0 + per : M;
+    const int blk = blockIdx.x, lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const bool is_h7 = blk < D.Fp / 32;
+    const int fb = is_h7 ? blk : blk - D.Fp / 32;
+    const int width = is_h7 ? D.Fp : D.Hp;
+    const float *plane = rec + (int64_t)(is_h7 ? D.r_h(7) : D.r_h9()) * MP;
     const float *gy = grad + (int64_t)D.g_gy() * MP, *ds = grad + (int64_t)D.g_dsig() * MP;
-    float s = 0.0f;
-    if (col < D.Fp) {
-        const float *h7 = rec + (int64_t)D.r_h(7) * MP;
-        for (int64_t m = m0; m < m1; ++m) s = fmaf(ds[m], h7[tf_offset(D.Fp, m, col)], s);
-    } else if (col < D.Fp + 3 * D.Hp) {
-        const int ch = (col - D.Fp) / D.Hp, k = (col - D.Fp) % D.Hp;
-        const float *h9 = rec + (int64_t)D.r_h9() * MP;
-        for (int64_t m = m0; m < m1; ++m) s = fmaf(gy[4 * m + ch], h9[tf_offset(D.Hp, m, k)], s);
-    } else {
-        const int ch = col - D.Fp - 3 * D.Hp;
-        for (int64_t m = m0; m < m1; ++m) s += ch == 0 ? ds[m] : gy[4 * m + ch - 1];
+    const int64_t tiles = MP / 32, per = (tiles + slices - 1) / slices;
+    const int64_t t0 = blockIdx.y * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+    double acc[3][16], ssum[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t m = t * 32 + i;
+        const f32x16 x = load_block(plane + t * 32 * width, fb, i, h);
+        if (is_h7) {
+            const double g = (double)ds[m];
+            if (h == 0) ssum[0] += g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] += g * (double)x[r];
+        } else {
+            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gy + 4 * m);
+            if (h == 0) { ssum[1] += (double)g4.x; ssum[2] += (double)g4.y; ssum[3] += (double)g4.z; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[0][r] += (double)g4.x * (double)x[r];
+                acc[1][r] += (double)g4.y * (double)x[r];
+                acc[2][r] += (double)g4.z * (double)x[r];
+            }
+        }
     }
-    partial[(int64_t)blockIdx.y * cols + col] = s;
+    auto over_samples = [&](double v) {   // sum over the 32 lanes of this half
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+        return v;
+    };
+    double *out = partial + (int64_t)blockIdx.y * cols;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (is_h7 && c > 0) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double v = over_samples(acc[c][r]);
+            const int k = 32 * fb + (r & 3) + 8 * (r >> 2) + 4 * h;      // the feature register r of lane half h holds
+            if (i == 0) out[is_h7 ? k : D.Fp + c * D.Hp + k] = v;
+        }
+    }
+    if (fb == 0) {   // the scalar sums ride on the first block of each plane (lane half 0 holds them)
+        if (is_h7) { const double v = over_samples(ssum[0]); if (lane == 0) out[D.Fp + 3 * D.Hp] = v; }
+        else {
+#pragma unroll
+            for (int c = 1; c < 4; ++c) { const double v = over_samples(ssum[c]); if (lane == 0) out[D.Fp + 3 * D.Hp + c] = v; }
+        }
+    }
 }
-__global__ void layered_thin_reduce_kernel(const Dims D, const float *__restrict__ partial, int slices,
-                                           float *__restrict__ g_params) {
+__global__ __launch_bounds__(64) void layered_thin_reduce_kernel(const Dims D, const double *__restrict__ partial,
+                                                                 int slices, float *__restrict__ g_params) {
     const int cols = D.Fp + 3 * D.Hp + 4;
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= cols) return;
-    float s = 0.0f;
-    for (int z = 0; z < slices; ++z) s += partial[(int64_t)z * cols + col];
+    const int col = blockIdx.x;
+    __shared__ double part[64];
+    double acc = 0.0;
+    for (int z = threadIdx.x; z < slices; z += 64) acc += partial[(int64_t)z * cols + col];   // fixed order per thread
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int t = 1; t < 64; ++t) acc += part[t];                                                // and across threads
+    const float s = (float)acc;
     if (col < D.Fp) { if (col < D.F) g_params[D.w[8] + col] = s; }
     else if (col < D.Fp + 3 * D.Hp) {
         const int ch = (col - D.Fp) / D.Hp, k = (col - D.Fp) % D.Hp;
@@ -623,7 +1069,7 @@ Sizes sizes(const Dims &D, int64_t rows, bool backward, int inputs) {
     s.consts = align256b(4 * (int64_t)D.c_floats());
     s.fwd_stream = (int64_t)stream_pairs(D, 0, 0) * PAIR_BYTES;
     s.dx_stream = backward ? (int64_t)stream_pairs(D, 1, inputs) * PAIR_BYTES : 0;
-    s.planes = align256b(4 * padded_rows(rows) * (int64_t)(backward ? D.gradw() : D.recw()));
+    s.planes = align256b(4 * lrows(rows) * (int64_t)(backward ? D.gradw() : D.recw()));
     return s;
 }
 
@@ -663,7 +1109,7 @@ NERF_API int64_t nerf_mlp_layered_plane(const nerf_net_t *net, int64_t rows, int
     const Sizes z = sizes(D, rows, false, 0);
     const int off = which == 0 ? D.r_pe() : which == 1 ? D.r_de() : which == 11 ? D.r_h9() : D.r_h(which - 2);
     if (width) *width = which == 0 ? D.Pp : which == 1 ? D.Dp : which == 11 ? D.Hp : D.Fp;
-    return z.consts + z.fwd_stream + 4 * (int64_t)off * padded_rows(rows);
+    return z.consts + z.fwd_stream + 4 * (int64_t)off * lrows(rows);
 }
 
 // workspace = [reverse stream (with the input-gradient passes)][gradient planes][thin partials][dW scratch]
@@ -673,7 +1119,7 @@ NERF_API int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t
     if (M <= 0) return 0;
     const Dims D = make_dims(d);
     const Sizes z = sizes(D, M, true, 1);
-    const int64_t thin = align256b(4 * (int64_t)THIN_SLICES * (D.Fp + 3 * D.Hp + 4));
+    const int64_t thin = align256b(8 * (int64_t)THIN_SLICES * (D.Fp + 3 * D.Hp + 4));
     const int items = 64 * ((D.Fp + 255) / 256) * ((D.Fp + 255) / 256) + 64;
     return z.dx_stream + z.planes + thin + nerf::dw_items_scratch_bytes(items) + 65536;
 }
@@ -703,7 +1149,7 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
     if (int rc = nerf::check_launch("nerf_mlp_layered_forward: pack")) return rc;
     for (int64_t r0 = 0; r0 < M; r0 += chunk) {
         const int64_t rows = M - r0 < chunk ? M - r0 : chunk;
-        const int64_t MP = padded_rows(rows);
+        const int64_t MP = lrows(rows);
         hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * D.Pp)), dim3(256), 0, s, pos + r0 * D.E_p, rows, MP,
                            D.E_p, D.Pp, planes + (int64_t)D.r_pe() * MP);
         hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * D.Dp)), dim3(256), 0, s, view_dir + r0 * D.E_d, rows, MP,
@@ -714,7 +1160,8 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
         a.rec = planes; a.grad = nullptr; a.M = rows; a.MP = MP;
         a.n_passes = fwd_num_passes(D); a.n_pairs = pa.n_pairs; a.inputs = 0;
         a.sigma = sigma + r0; a.rgb = rgb + 3 * r0;
-        if (int rc = launch_program(false, a, s)) return rc;
+        // narrow networks: register-resident, planes written only when the whole batch is recorded for a backward
+        if (int rc = narrow_ok(D) ? launch_narrow(false, record_rows >= M, a, s) : launch_program(false, a, s)) return rc;
     }
     return NERF_OK;
 }
@@ -740,7 +1187,7 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
                  "nerf_mlp_layered_backward: null pointer");
     NERF_REQUIRE(M < (int64_t)1 << 31, "nerf_mlp_layered_backward: more than 2^31 samples per call");
     const int inputs = (g_pos || g_view_dir) ? 1 : 0;
-    const int64_t MP = padded_rows(M);
+    const int64_t MP = lrows(M);
     const Sizes zr = sizes(D, M, false, 0), zw = sizes(D, M, true, 1);
     const char *rbase = static_cast<const char *>(record);
     const float *consts = reinterpret_cast<const float *>(rbase);
@@ -748,8 +1195,8 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
     char *wbase = static_cast<char *>(workspace);
     float *dstream = reinterpret_cast<float *>(wbase);
     float *grad = reinterpret_cast<float *>(wbase + zw.dx_stream);
-    float *thin = reinterpret_cast<float *>(wbase + zw.dx_stream + zw.planes);
-    const int64_t thin_bytes = align256b(4 * (int64_t)THIN_SLICES * (D.Fp + 3 * D.Hp + 4));
+    double *thin = reinterpret_cast<double *>(wbase + zw.dx_stream + zw.planes);
+    const int64_t thin_bytes = align256b(8 * (int64_t)THIN_SLICES * (D.Fp + 3 * D.Hp + 4));
     char *dw_scratch = wbase + zw.dx_stream + zw.planes + thin_bytes;
 
     PackArgs pa; pa.D = D; pa.P = params; pa.dx = 1; pa.inputs = inputs; pa.n_pairs = stream_pairs(D, 1, inputs);
@@ -760,7 +1207,7 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
     a.rec = rec; a.grad = grad; a.M = M; a.MP = MP;
     a.n_passes = dx_num_passes(D, inputs); a.n_pairs = pa.n_pairs; a.inputs = inputs;
     a.sigma_in = sigma; a.rgb_in = rgb; a.g_sigma = g_sigma; a.g_rgb = g_rgb;
-    if (int rc = launch_program(true, a, s)) return rc;
+    if (int rc = narrow_ok(D) ? launch_narrow(true, inputs != 0, a, s) : launch_program(true, a, s)) return rc;
     if (g_pos) hipLaunchKernelGGL(plane_to_rows_kernel, dim3(grid_for(M * D.E_p)), dim3(256), 0, s,
                                   grad + (int64_t)D.g_gp() * MP, M, D.E_p, D.Pp, g_pos);
     if (g_view_dir) hipLaunchKernelGGL(plane_to_rows_kernel, dim3(grid_for(M * D.E_d)), dim3(256), 0, s,
@@ -768,11 +1215,11 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
     // thin rows
     {
         const int cols = D.Fp + 3 * D.Hp + 4;
-        int slices = (int)((M + 2047) / 2048);
+        int slices = (int)(MP / 32 / 16);          // >= 16 tiles per slice
         if (slices > THIN_SLICES) slices = THIN_SLICES;
         if (slices < 1) slices = 1;
-        hipLaunchKernelGGL(layered_thin_kernel, dim3((cols + 63) / 64, slices), dim3(64), 0, s, D, rec, grad, M, MP, thin);
-        hipLaunchKernelGGL(layered_thin_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, D, thin, slices, g_params);
+        hipLaunchKernelGGL(layered_thin_kernel, dim3((D.Fp + D.Hp) / 32, slices), dim3(64), 0, s, D, rec, grad, MP, slices, thin);
+        hipLaunchKernelGGL(layered_thin_reduce_kernel, dim3(cols), dim3(64), 0, s, D, thin, slices, g_params);
         if (int rc = nerf::check_launch("nerf_mlp_layered_backward: thin rows")) return rc;
     }
     // dW / db: windows of <= 256 x 256 over (dY plane of the layer, its input plane(s))
