@@ -20,6 +20,27 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- cross-lane moves on the vector ALU (DPP / permlane swaps): a ds_bpermute-based __shfl costs an LDS round trip
+// (~100+ cycles in a dependent chain: the 21 exchange stages of the sort and the scans of a ray were ~5 k cycles of it)
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ unsigned dpp_mov(unsigned old, unsigned src) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, BANK_MASK, true);
+}
+// value of lane (lane ^ D), D a power of two
+template <int D>
+__device__ __forceinline__ unsigned lane_xor(unsigned v, int lane) {
+    if (D == 1) return dpp_mov<0xB1>(0u, v);                      // quad_perm [1,0,3,2]
+    if (D == 2) return dpp_mov<0x4E>(0u, v);                      // quad_perm [2,3,0,1]
+    if (D == 4) return dpp_mov<0x114, 0xF, 0xA>(dpp_mov<0x104, 0xF, 0x5>(0u, v), v);   // row_shl:4 into banks 0,2; row_shr:4 into 1,3
+    if (D == 8) return dpp_mov<0x128>(0u, v);                     // row_ror:8
+    if (D == 16) {   // v_permlane16_swap: odd rows of the first operand <-> even rows of the second
+        const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? p[0] : p[1];
+    }
+    const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // upper half of the first <-> lower half of the second
+    return (lane & 32) ? p[0] : p[1];
+}
+
 __device__ __forceinline__ int ceil_log2_i(int x) {
     if (x <= 2) return 1;
     return 32 - __builtin_clz((unsigned)(x - 1));
@@ -208,7 +229,9 @@ __device__ __forceinline__ bool bitonic_sort_row(int lane, int S, const float *i
                 const bool low = (lane & d) == 0;                                // this lane holds the lower element
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const unsigned y = (unsigned)__shfl_xor((int)x[k], d, WAVE);
+                    const unsigned y = stride == 4 ? lane_xor<1>(x[k], lane) : stride == 8 ? lane_xor<2>(x[k], lane)
+                                     : stride == 16 ? lane_xor<4>(x[k], lane) : stride == 32 ? lane_xor<8>(x[k], lane)
+                                     : stride == 64 ? lane_xor<16>(x[k], lane) : lane_xor<32>(x[k], lane);
                     const unsigned lo = x[k] < y ? x[k] : y, hi = x[k] < y ? y : x[k];
                     x[k] = (low == up_lane) ? lo : hi;
                 }
@@ -260,6 +283,11 @@ __device__ __forceinline__ void hierarchical_ray(int lane, int Sc, int Sf, const
                                         const float *__restrict__ u2_row, const float *__restrict__ u3_row,
                                         int64_t *__restrict__ bin_idx_row, float *scratch, float *t_srt) {
     const int S = Sc + Sf;
+    // the fine draws of the first search round, requested before anything else: their HBM latency (~2 k cycles in
+    // front of the search) runs under the pdf / cdf phases
+    const bool pre_a = lane < Sf, pre_b = lane + WAVE < Sf;
+    const float pre_ya = pre_a ? u2_row[lane] : 0.0f, pre_yb = pre_b ? u2_row[lane + WAVE] : 0.0f;
+    const float pre_ja = pre_a ? u3_row[lane] : 0.0f, pre_jb = pre_b ? u3_row[lane + WAVE] : 0.0f;
     float *t_raw = scratch;                  // S   coarse then fine, unsorted
     float *w = t_raw + ((S + 3) & ~3);       // Sc  weights + 1e-5, then pdf
     float *cdf = w + ((Sc + 3) & ~3);        // Sc
@@ -308,11 +336,16 @@ __device__ __forceinline__ void hierarchical_ray(int lane, int Sc, int Sf, const
             emin = e < emin ? e : emin;
             emax = e > emax ? e : emax;
         }
-#pragma unroll
-        for (int off = WAVE / 2; off > 0; off >>= 1) {
-            const int lo = __shfl_xor(emin, off, WAVE), hi = __shfl_xor(emax, off, WAVE);
-            emin = lo < emin ? lo : emin;
-            emax = hi > emax ? hi : emax;
+        {   // butterfly over the wave: every lane ends with the row's extremes
+            auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+            unsigned hi = (unsigned)emax, lo = (unsigned)(255 - emin);
+            hi = mx(hi, lane_xor<1>(hi, lane)); lo = mx(lo, lane_xor<1>(lo, lane));
+            hi = mx(hi, lane_xor<2>(hi, lane)); lo = mx(lo, lane_xor<2>(lo, lane));
+            hi = mx(hi, lane_xor<4>(hi, lane)); lo = mx(lo, lane_xor<4>(lo, lane));
+            hi = mx(hi, lane_xor<8>(hi, lane)); lo = mx(lo, lane_xor<8>(lo, lane));
+            hi = mx(hi, lane_xor<16>(hi, lane)); lo = mx(lo, lane_xor<16>(lo, lane));
+            hi = mx(hi, lane_xor<32>(hi, lane)); lo = mx(lo, lane_xor<32>(lo, lane));
+            emax = (int)hi; emin = 255 - (int)lo;
         }
         const bool exact = !__any(!plain) && (emax - emin) + ceil_log2_i(Sc) <= 27;
         double run = 0.0;
@@ -355,8 +388,8 @@ __device__ __forceinline__ void hierarchical_ray(int lane, int Sc, int Sf, const
         for (int f0 = 0; f0 < Sf; f0 += 2 * WAVE) {
             const int fa = f0 + lane, fb = fa + WAVE;
             const bool has_a = fa < Sf, has_b = fb < Sf;
-            const float ya = has_a ? u2_row[fa] : 0.0f, yb = has_b ? u2_row[fb] : 0.0f;
-            const float ja = has_a ? u3_row[fa] : 0.0f, jb = has_b ? u3_row[fb] : 0.0f;
+            const float ya = f0 == 0 ? pre_ya : (has_a ? u2_row[fa] : 0.0f), yb = f0 == 0 ? pre_yb : (has_b ? u2_row[fb] : 0.0f);
+            const float ja = f0 == 0 ? pre_ja : (has_a ? u3_row[fa] : 0.0f), jb = f0 == 0 ? pre_jb : (has_b ? u3_row[fb] : 0.0f);
             int pa = 0, pb = 0;   // entries known to be <= y
             for (int step = top; step > 0; step >>= 1) {
                 const int na = pa + step, nb = pb + step;
@@ -389,13 +422,25 @@ __device__ __forceinline__ void hierarchical_ray(int lane, int Sc, int Sf, const
 // ---- quadrature_integrator.py:41-65 for one ray: lane = sample, 64 samples per step.  The exclusive prefix sum of
 // sigma * delta is a wave-level scan with lane shuffles in double (ATen's CPU cumsum accumulates in double),
 // carried across steps.
+// inclusive prefix sum over the 64 lanes: the DPP scan (row_shr 1, 2, 3; row_shr:4 / :8 into the upper banks;
+// row_bcast 15 / 31 across rows), the two halves of a double moved separately
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = dpp_mov<CTRL, ROW_MASK, BANK_MASK>(0u, (unsigned)b);
+    const unsigned hi = dpp_mov<CTRL, ROW_MASK, BANK_MASK>(0u, (unsigned)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const double up = __shfl_up(v, off, WAVE);
-        if (lane >= off) v += up;
-    }
-    return v;
+    (void)lane;
+    double s = v + dpp_mov_f64<0x111, 0xF, 0xF>(v);      // + lane - 1   (zeros shift into a row)
+    s += dpp_mov_f64<0x112, 0xF, 0xF>(v);                // + lane - 2
+    s += dpp_mov_f64<0x113, 0xF, 0xF>(v);                // + lane - 3
+    s += dpp_mov_f64<0x114, 0xF, 0xE>(s);                // groups of 4 -> 8 (banks 1..3)
+    s += dpp_mov_f64<0x118, 0xF, 0xC>(s);                // -> 16 (banks 2, 3)
+    s += dpp_mov_f64<0x142, 0xA, 0xF>(s);                // row_bcast:15 into rows 1, 3
+    s += dpp_mov_f64<0x143, 0xC, 0xF>(s);                // row_bcast:31 into rows 2, 3
+    return s;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
