@@ -61,7 +61,7 @@ def layered_plane(rec, net, M, which):
     off = lib.nerf_mlp_layered_plane(net.ref, M, which, ctypes.byref(width))
     assert off >= 0 and off % 4 == 0
     W = width.value
-    MP = (M + 127) // 128 * 128
+    MP = (M + 255) // 256 * 256          # rows of this family's planes: whole 256-sample tiles
     raw = rec.cpu().numpy().view(np.float32)[off // 4: off // 4 + MP * W]
     # tf_offset(width, m, k) is linear in the tile index: build the index map of one 32-sample tile once
     tile = np.array([[lib.nerf_mlp_plane_offset(W, m, k) for k in range(W)] for m in range(32)], np.int64)

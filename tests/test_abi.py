@@ -48,13 +48,13 @@ def test_network_descriptions_choose_the_kernel_family():
         assert lib.nerf_mlp_path(n) == path, (lp, ld, inc, feat)
         assert lib.nerf_mlp_param_count(n) == synth.param_count(e_p, e_d, feat)
         assert (lib.nerf_mlp_packed_bytes(n) > 0) == (path == 0)      # the layered family packs inside its calls
-        # record = constant block + forward stream + 128 padded rows of planes (two inputs, h0..h7, fc_8[1:], h9)
+        # record = constant block + forward stream + 256 padded rows of planes (two inputs, h0..h7, fc_8[1:], h9)
         r32 = lambda v: (v + 31) // 32 * 32
-        planes = 128 * 4 * (r32(e_p) + r32(e_d) + 9 * r32(feat) + r32(feat // 2))
+        planes = 256 * 4 * (r32(e_p) + r32(e_d) + 9 * r32(feat) + r32(feat // 2))
         assert lib.nerf_mlp_layered_record_bytes(n, 10) > planes
         import ctypes as _ct
         w = _ct.c_int(0)
-        assert lib.nerf_mlp_layered_plane(n, 10, 11, _ct.byref(w)) == lib.nerf_mlp_layered_record_bytes(n, 10) - 128 * 4 * r32(feat // 2)
+        assert lib.nerf_mlp_layered_plane(n, 10, 11, _ct.byref(w)) == lib.nerf_mlp_layered_record_bytes(n, 10) - 256 * 4 * r32(feat // 2)
         assert w.value == r32(feat // 2)
         assert lib.nerf_mlp_layered_workspace_bytes(n, 1000) > 0
     # encoders the kernels do not know (levels < 0): any widths, pre-encoded entries only
@@ -102,7 +102,7 @@ def test_render_is_fused_is_a_host_side_rule():
 def test_entry_points_refuse_what_they_cannot_serve_before_touching_the_gpu():
     """Argument validation is host code and runs without a GPU: a network outside the fused family is refused by the
     fused entries with NERF_ERR_UNSUPPORTED (and pointed at nerf_mlp_layered_*), raw-input entries need encode
-    levels, the bf16 variant is bound to the shipped network, SH degrees beyond 5 do not exist, M = 0 is a no-op."""
+    levels, the bf16 variant needs the levels of both encoders, SH degrees beyond 5 do not exist, M = 0 is a no-op."""
     import ctypes
     lib = _lib.load()
     OK, ARG, UNSUPPORTED = 0, 1, 2
@@ -119,9 +119,12 @@ def test_entry_points_refuse_what_they_cannot_serve_before_touching_the_gpu():
     sh = net(16, 16, 256, -1, 0, -1, 0)                                            # fused widths, encoders unknown
     assert lib.nerf_mlp_forward(sh, p, p, p, 4, 0, p, p, None, None) == UNSUPPORTED and b"levels" in lib.nerf_amd_last_error()
     assert lib.nerf_render_pass(sh, p, p, p, 4, 64, 0, p, 0.1, None, p, None, None, p, p, None, None, None, None) == UNSUPPORTED
+    assert lib.nerf_mlp_forward_bf16(sh, p, p, p, 4, p, p, None) == UNSUPPORTED and b"levels" in lib.nerf_amd_last_error()
+    mixed = net(39, 12, 256, 6, 1, 2, 0)                                            # include_input differs between the two
+    assert lib.nerf_mlp_forward_bf16(mixed, p, p, p, 4, p, p, None) == UNSUPPORTED
+    assert lib.nerf_mlp_forward_bf16(f128, p, p, p, 4, p, p, None) == UNSUPPORTED   # bf16: the fused family only
     other = net(39, 15, 256, 6, 1, 2, 1)
-    assert lib.nerf_mlp_forward_bf16(other, p, p, p, 4, p, p, None) == UNSUPPORTED and b"shipped" in lib.nerf_amd_last_error()
-    assert lib.nerf_mlp_packed_bf16_bytes(other) > 0                                # the stream format itself is width-generic
+    assert lib.nerf_mlp_packed_bf16_bytes(other) > 0                                # run-time levels: served since round 4
     bad = net(63, 27, 256, 9, 1, 4, 1)
     assert lib.nerf_mlp_forward(bad, p, p, p, 4, 1, p, p, None, None) == ARG
     assert lib.nerf_mlp_layered_forward(bad, p, p, p, 4, p, p, p, 4, None) == ARG

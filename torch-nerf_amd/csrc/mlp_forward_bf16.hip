@@ -157,9 +157,11 @@ __device__ __forceinline__ void pack_block(const f32x16 &x, bf16x8 (&frag)[2]) {
 // k0 = 32 blk + 8 (2 s + (j >> 1)) + 2 (j & 1) + 4 h.  Octave by octave, each word is emitted as soon as its (at
 // most four) candidate features exist, so that only ~2 octaves of features are live at any time (the first
 // version evaluated all 63 features first: 64 live floats on top of 128 accumulators spill at 256 registers).
-template <int LEVELS, int NBLK>
-__device__ __forceinline__ void encode_frags(float x, float y, float z, int h, bf16x8 (&frag)[NBLK][2]) {
-    constexpr int NF = 32 * NBLK, KMAX = 3 + 6 * LEVELS;
+// RT: `levels` <= LEVELS octaves at run time (the features of the others are zero, like the weight columns behind
+// them in the stream); INC = include_input.  The shipped configuration is <10 | 4, ., true, false>.
+template <int LEVELS, int NBLK, bool INC = true, bool RT = false>
+__device__ __forceinline__ void encode_frags(float x, float y, float z, int h, bf16x8 (&frag)[NBLK][2], int levels = LEVELS) {
+    constexpr int NF = 32 * NBLK, RAW = INC ? 3 : 0, KMAX = RAW + 6 * LEVELS;
     float F[NF + 8];   // static indices only: the compiler keeps just the live window in registers
 #pragma unroll
     for (int k = 0; k < NF + 8; ++k) F[k] = 0.0f;
@@ -167,7 +169,7 @@ __device__ __forceinline__ void encode_frags(float x, float y, float z, int h, b
     float sn[3], cs[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        F[c] = v[c];
+        if (INC) F[c] = v[c];
         sincos_cw<false>(v[c], sn[c], cs[c]);   // |coordinate| itself is the only argument: no large-range issue below 3e4
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -194,13 +196,14 @@ __device__ __forceinline__ void encode_frags(float x, float y, float z, int h, b
     for (int f = 0; f < LEVELS; ++f) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (3 + 6 * f + c < NF) F[3 + 6 * f + c] = sn[c];
-            if (3 + 6 * f + 3 + c < NF) F[3 + 6 * f + 3 + c] = cs[c];
+            const bool on = !RT || f < levels;      // (wave-uniform)
+            if (RAW + 6 * f + c < NF) F[RAW + 6 * f + c] = on ? sn[c] : 0.0f;
+            if (RAW + 6 * f + 3 + c < NF) F[RAW + 6 * f + 3 + c] = on ? cs[c] : 0.0f;
             const float s2 = 2.0f * sn[c] * cs[c];
             cs[c] = fmaf(-2.0f * sn[c], sn[c], 1.0f);
             sn[c] = s2;
         }
-        emit_upto(3 + 6 * (f + 1) < NF ? 3 + 6 * (f + 1) : NF);
+        emit_upto(RAW + 6 * (f + 1) < NF ? RAW + 6 * (f + 1) : NF);
     }
     emit_upto(NF);   // zero tail beyond KMAX
     static_assert(KMAX <= NF, "encoding wider than the fragment blocks");
@@ -210,7 +213,11 @@ __device__ __forceinline__ void encode_frags(float x, float y, float z, int h, b
         for (int s = 0; s < 2; ++s) frag[blk][s] = __builtin_bit_cast(bf16x8, words[blk][s]);
 }
 
-__global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_bf16_kernel(const char *__restrict__ packed,
+// MODE 0: the shipped encoders (compile-time recurrences; BASELINE configs[2]); 1 / 2: PositionalEncoders of run-time
+// levels (<= 10 for the position, <= 4 | 5 for the direction) with / without include_input -- every other network of
+// the fused family (runner_utils.py:584-612)
+template <int MODE>
+__global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_bf16_kernel(const Net net, const char *__restrict__ packed,
                                                                           const float *__restrict__ pos,
                                                                           const float *__restrict__ dir, int64_t M,
                                                                           float *__restrict__ sigma_out,
@@ -275,7 +282,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_bf16_kernel(const c
 
         // encoded position as B fragments, evaluated on demand (fc_in and the fc_5 skip connection)
         auto position_frags = [&](bf16x8 (&pe)[2][2]) {  // [blk][s]
-            encode_frags<DEFAULT_NET.l_pos, 2>(raw[0], raw[1], raw[2], h, pe);
+            if (MODE == 0) encode_frags<DEFAULT_NET.l_pos, 2>(raw[0], raw[1], raw[2], h, pe);
+            else encode_frags<10, 2, MODE == 1, true>(raw[0], raw[1], raw[2], h, pe, net.l_pos);
         };
         // one sub-step = two 32-feature input blocks against all NFB output blocks
         auto sub_step = [&](const char *w, const bf16x8 (&b0)[2], const bf16x8 (&b1)[2], auto nfb_tag) {
@@ -396,7 +404,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_bf16_kernel(const c
             mma_chunk16<4, 0>(acc, act[5], w + 2 * B16_HALF_CHUNK_BYTES, offs, pipe);
             pipe.issue_done();
             bf16x8 de[1][2];
-            encode_frags<DEFAULT_NET.l_dir, 1>(raw[3], raw[4], raw[5], h, de);
+            if (MODE == 0) encode_frags<DEFAULT_NET.l_dir, 1>(raw[3], raw[4], raw[5], h, de);
+            else encode_frags<(MODE == 1 ? 4 : 5), 1, MODE == 1, true>(raw[3], raw[4], raw[5], h, de, net.l_dir);
             w = ring + pipe.acquire();
             mma_chunk16<4, PIECES>(acc, act[6], w, offs, pipe);
             mma_chunk16<4, 0>(acc, act[7], w + B16_HALF_CHUNK_BYTES, offs, pipe);
@@ -439,20 +448,21 @@ NERF_API int nerf_mlp_forward_bf16(const nerf_net_t *net_abi, const void *packed
                                    const float *view_dir, int64_t M, float *sigma, float *rgb, nerf_stream_t stream) {
     mlp::Net net;
     if (int rc = nerf::fused_net(net_abi, net, "nerf_mlp_forward_bf16")) return rc;
-    if (!net.is_default())   // BASELINE configs[2] is the shipped network; its encodings are compile-time recurrences
-        return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_mlp_forward_bf16: built for the shipped NeRF(63, 27) with "
-                                                "encode levels 10 / 4; other networks run the fp32 kernels");
+    if (!nerf::raw_inputs_ok(net) || net.inc_pos != net.inc_dir)
+        return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_mlp_forward_bf16: the kernel encodes raw points: nerf_net_t needs the "
+                                                "levels of both PositionalEncoders (one include_input for both)");
     NERF_REQUIRE(M >= 0, "nerf_mlp_forward_bf16: negative M");
     if (M == 0) return NERF_OK;
     NERF_REQUIRE(packed_bf16 && pos && view_dir && sigma && rgb, "nerf_mlp_forward_bf16: null pointer");
-    static nerf::DeviceMask configured{0};
-    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_forward_bf16_kernel), W8_LDS_BYTES,
-                                          configured, "nerf_mlp_forward_bf16: LDS attribute"))
+    const int mode = net.is_default() ? 0 : net.inc_pos ? 1 : 2;
+    auto kern = mode == 0 ? mlp_forward_bf16_kernel<0> : mode == 1 ? mlp_forward_bf16_kernel<1> : mlp_forward_bf16_kernel<2>;
+    static nerf::DeviceMask configured[3] = {{0}, {0}, {0}};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), W8_LDS_BYTES, configured[mode],
+                                          "nerf_mlp_forward_bf16: LDS attribute"))
         return rc;
     const int cus = nerf::device_cus();
     const int64_t ntiles = (M + TILE - 1) / TILE;
-    hipLaunchKernelGGL(mlp_forward_bf16_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(64 * WAVES),
-                       W8_LDS_BYTES, nerf::as_stream(stream), static_cast<const char *>(packed_bf16), pos,
-                       view_dir, M, sigma, rgb);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(64 * WAVES), W8_LDS_BYTES,
+                       nerf::as_stream(stream), net, static_cast<const char *>(packed_bf16), pos, view_dir, M, sigma, rgb);
     return nerf::check_launch("nerf_mlp_forward_bf16");
 }

@@ -247,6 +247,12 @@ class Net:
     def is_shipped(self) -> bool:
         return self.key == (63, 27, 256, 10, 1, 4, 1)
 
+    @property
+    def bf16_ok(self) -> bool:
+        """True if the bf16-MFMA inference kernel serves this network (BASELINE configs[2]): the fused family behind two
+        PositionalEncoders that share one include_input (the yaml has ONE such knob: positional_encoding.yaml:4)."""
+        return self.fused and self.knows_encoders and self.key[4] == self.key[6]
+
     def __repr__(self):
         return f"Net{self.key}"
 

@@ -107,7 +107,7 @@ class VolumeRenderer(object):
         dev = t_bins.device
         origin, direction = ray_bundle.ray_origin.to(dev), ray_bundle.ray_dir.to(dev)
         u1, u2, u3 = self.sampler.draw_uniforms(origin.shape[0], n_coarse, n_fine if hierarchical else 0, dev)
-        bf16 = bool(getattr(net, "bf16_inference", False)) and spec.is_shipped
+        bf16 = bool(getattr(net, "bf16_inference", False)) and spec.bf16_ok
         if bf16:
             packed = net._stream_bf16()
         if not hierarchical:
