@@ -370,7 +370,23 @@ def frame_leg(nets, cam, rank, world, device, dist_on=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     digest = hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()[:16]
+    gather_ms = None
+    if dist_on:    # the frame's ONE collective on its own: the same (H*W/world, 3) slabs, rendering excluded
+        per = (H * W + world - 1) // world
+        slab = torch.zeros((per, 3), device=device)
+        full = torch.empty((world * per, 3), device=device)
+        times = []
+        for _ in range(4):
+            fence()
+            t0 = time.perf_counter()
+            dist.all_gather_into_tensor(full, slab)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        t = torch.tensor([min(times[1:])], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gather_ms = t.item() * 1e3
     out = {"ms": dt * 1e3, "rays_per_s": H * W / dt, "rays": H * W, "n_gpus": world, "scaling": "strong",
+           "gather_ms": gather_ms,
            "image_sha256_16": digest,
            "what": f"{W}x{H} frame, 64+128 samples, fp32, contiguous pixel ranges over {world} rank(s), "
                    "all-gather of the (H*W/world, 3) slabs included"}
@@ -379,6 +395,57 @@ def frame_leg(nets, cam, rank, world, device, dist_on=None):
         same = torch.tensor([float(torch.equal(solo, img))], device=device)
         dist.all_reduce(same, op=dist.ReduceOp.MIN)          # equal on EVERY rank
         out["equals_one_rank_image"] = bool(same.item())
+    return out
+
+
+def frame_api_leg(renderer, scene_c, scene_f, cam_pose, focal):
+    """The whole 800x800 frame through the CLASS API, call for call as the reference's runners do it:
+    frame_api = _visualize_scene (runners/runner_utils.py:872-908): render_scene(default_scene, num_pixels=H*W,
+                num_samples=64, num_ray_batch=H*W // 4096) -> render_scene(fine_scene, ..., (64, 128), pixel_indices,
+                weights, num_ray_batch) -> reshape / permute to (C, H, W);
+    validate  = the per-view body of validate_one_epoch (runners/train.py:285-330): a fresh PerspectiveCamera, the same
+                two calls, MSE / PSNR against the ground-truth view.
+    Peak device memory of the frame is reported (the API materialises the whole-frame draws and the (N, S) weights)."""
+    import torch_nerf.src.renderer.cameras as cameras
+    total = H * W
+    dev_i = torch.cuda.current_device()
+
+    def frame():
+        pred, idx, w = renderer.render_scene(scene_c, num_pixels=total, num_samples=N_COARSE, project_to_ndc=False,
+                                             device=dev_i, num_ray_batch=total // RAYS)
+        pred, _, _ = renderer.render_scene(scene_f, num_pixels=total, num_samples=(N_COARSE, N_FINE),
+                                           project_to_ndc=False, pixel_indices=idx, weights=w, device=dev_i,
+                                           num_ray_batch=total // RAYS)
+        return pred.reshape(H, W, -1).permute(2, 0, 1)
+
+    out = {}
+    with torch.no_grad():
+        frame()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        t0 = time.perf_counter()
+        img = frame()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["frame_api"] = {"ms": dt * 1e3, "rays_per_s": total / dt, "rays": total,
+                            "peak_mem_gib": (torch.cuda.max_memory_allocated() - base) / 2 ** 30,
+                            "finite": bool(torch.isfinite(img).all()),
+                            "what": "runner_utils.py:872-908: two render_scene calls over the whole frame "
+                                    "(num_ray_batch = H*W // 4096), fp32, 1 GPU"}
+        gt = torch.rand((H, W, 3))
+        loss_func = torch.nn.MSELoss()
+        t0 = time.perf_counter()
+        renderer.camera = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
+                                                    cam_pose, NEAR, FAR)
+        pred = frame()[None]
+        pixel_gt = gt.reshape(H, W, -1).permute(2, 0, 1)[None].cuda()
+        mse = loss_func(pixel_gt, pred).item()
+        psnr = -10.0 * np.log10(max(mse, 1e-12))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["validate"] = {"ms": dt * 1e3, "rays_per_s": total / dt, "psnr_vs_random_gt_db": float(psnr),
+                           "what": "train.py:285-330 per view: camera + two whole-frame render_scene calls + MSE / PSNR"}
     return out
 
 
@@ -495,6 +562,24 @@ def configs_leg(nets, flats, device):
     img = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, True, seed=2, single_rank=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # ---- configs[2]: "Blender ship, 800x800, 64+128, bf16 MLP weights on MFMA": the whole frame on the bf16 path and
+    # its PSNR against the fp32 frame of the same networks, pose and draws
+    cam8 = cameras.PerspectiveCamera({"f_x": float(synth.blender_focal(W)), "f_y": float(synth.blender_focal(W)),
+                                      "img_width": W, "img_height": H},
+                                     torch.from_numpy(synth.pose_spherical(37.0, -30.0, 4.0)), NEAR, FAR)
+    ref32 = shard.render_frame(cam8, nets[0], nets[1], N_COARSE, N_FINE, False, seed=4, single_rank=True)
+    shard.render_frame(cam8, nets[0], nets[1], N_COARSE, N_FINE, False, seed=4, single_rank=True, bf16=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    img16 = shard.render_frame(cam8, nets[0], nets[1], N_COARSE, N_FINE, False, seed=4, single_rank=True, bf16=True)
+    torch.cuda.synchronize()
+    dt16 = time.perf_counter() - t0
+    mse16 = torch.mean((img16.double() - ref32.double()) ** 2).item()
+    out["ship_bf16"] = {"ms": dt16 * 1e3, "rays_per_s": H * W / dt16, "rays": H * W,
+                        "psnr_vs_fp32_frame_db": float(-10.0 * np.log10(max(mse16, 1e-20))),
+                        "max_abs_err_vs_fp32_frame": float((img16 - ref32).abs().max().item()),
+                        "what": "Blender geometry 800x800, 64+128, bf16 weights + layer inputs on v_mfma_f32_32x32x16_bf16 "
+                                "(fp32 accumulate), whole frame on 1 GPU through shard.render_frame(bf16=True)"}
     out["llff"] = {"ms": dt * 1e3, "rays_per_s": Hl * Wl / dt, "rays": Hl * Wl, "finite": bool(torch.isfinite(img).all()),
                    "image_sha256_16": hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()[:16],
                    "what": "LLFF fern geometry 1008x756, NDC rays, t in [0,1], 64+128, fp32, 1 GPU, full frame"}
@@ -622,9 +707,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary fwd+bwd+Adam measurement")
-    ap.add_argument("--train", action="store_true", help="with --gpus > 1: also run the data-parallel training leg "
-                    "(gradient all-reduce inside the optimizer); off by default so that a failure on one rank can "
-                    "never stall the headline line")
+    ap.add_argument("--train", action="store_true", help="(accepted for compatibility: the data-parallel training leg "
+                    "-- gradient all-reduce inside the optimizer -- now runs by default for every --gpus; the headline "
+                    "line is out before it starts, so a failure there cannot erase the measurement; --no-train skips it)")
+    ap.add_argument("--fault-rank", type=int, default=-1, help="test hook: this rank exits (code 17) right after the "
+                    "rendezvous, before the first data collective -- the others must fail within --dist-timeout, not hang")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-MFMA render measurement")
     ap.add_argument("--no-frame", action="store_true", help="skip the 800x800 sharded full-frame leg")
     ap.add_argument("--no-stages", action="store_true", help="skip the HBM-bound stage measurements")
@@ -657,7 +744,10 @@ def main():
     if args.launch_check:
         seen = torch.ones(1)
         if world > 1:
-            dist.init_process_group("gloo" if args.backend != "nccl" or not torch.cuda.is_available() else "nccl")
+            dist.init_process_group("gloo" if args.backend != "nccl" or not torch.cuda.is_available() else "nccl",
+                                    timeout=datetime.timedelta(seconds=args.dist_timeout))
+            if rank == args.fault_rank:      # a rank that dies between the rendezvous and the first collective
+                os._exit(17)
             dist.all_reduce(seen)
             dist.barrier()
         if rank == 0:
@@ -688,6 +778,8 @@ def main():
             dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
             dist.init_process_group(args.backend, timeout=tmo)
+        if rank == args.fault_rank:
+            os._exit(17)
         seen = torch.ones(1, device=device)
         dist.all_reduce(seen)                      # every rank really is on the communicator
         ranks_seen = int(seen.item())
@@ -742,10 +834,15 @@ def main():
         events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     step_events.append(e_end)
     per_step = [a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:])]
+    per_rank = None
     if dist_on:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = torch.empty((world,), device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, mine)       # a bad N-GPU number must be diagnosable from the line alone
+        ms = (every / args.steps * 1e3).tolist()
+        per_rank = {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "rank_of_max": int(np.argmax(ms)),
+                    "ms_per_step": [round(v, 4) for v in ms]}
+        elapsed = float(every.max().item())
 
     # ---- dominant kernel: the fused render pass (sampling + encode + MLP + integral in one kernel), two launches
     # per step: coarse pass M = 4096 x 64 and fine pass M = 4096 x 192 samples.  achieved = algorithmic MLP FLOPs
@@ -786,6 +883,7 @@ def main():
                    "parallelism": f"ray-shard x{world}" + (" + all-gather" if dist_on else "")},
         "rccl_ranks_seen": ranks_seen,
         "backend": args.backend if dist_on else None,
+        "per_rank": per_rank,
         "roofline": roofline,
     }
     # With a process group up the headline line leaves NOW: a secondary leg that hangs in a collective (or a rank
@@ -810,12 +908,20 @@ def main():
 
     if not args.no_frame:       # collective: every rank takes part
         result["frame"] = guarded("frame", lambda: frame_leg(nets, cam, rank, world, device, dist_on))
+    if rank == 0 and world == 1 and not args.no_frame:
+        api = guarded("frame_api", lambda: frame_api_leg(renderer, scene_c, scene_f, pose, focal))
+        if "error" in api:
+            result["frame_api"] = api
+        else:
+            result.update(api)
+            if isinstance(result.get("frame"), dict) and "ms" in result["frame"]:
+                result["frame_api"]["vs_frame_leg"] = result["frame_api"]["ms"] / result["frame"]["ms"]
     if rank == 0 and world == 1 and not args.no_configs:     # before the train leg: that one UPDATES the networks
         result["configs"] = guarded("configs", lambda: configs_leg(nets, flats, device))
     if world == 1 and not args.no_bf16:
         result["bf16"] = guarded("bf16", lambda: bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank,
                                                           args.steps, 3))
-    if (world == 1 and not args.no_train) or (world > 1 and args.train):
+    if not args.no_train:       # world > 1: data-parallel (one gradient all-reduce per step inside FusedAdam)
         result["train"] = guarded("train", lambda: train_leg(renderer, scene_c, scene_f, nets, pix, device,
                                                              local_rank, max(3, args.steps // 4), 2, world))
     if rank == 0 and world == 1 and not args.no_runner_loop and not args.no_train:

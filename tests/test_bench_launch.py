@@ -43,10 +43,29 @@ def test_mismatched_launcher_world_is_refused():
     assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr
 
 
+def test_a_rank_that_dies_before_the_first_collective_ends_the_run():
+    """The failure path of the N-rank launch: rank 1 exits between the rendezvous and the first
+    data collective.  The run must END -- launcher return code != 0 well inside --dist-timeout + launcher teardown --
+    with no headline line, instead of hanging in the surviving rank's all-reduce.  Child processes only."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--launch-check", "--fault-rank", "1", "--dist-timeout", "20"],
+                         capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], out.stdout[-500:]
+    assert time.time() - t0 < 120
+
+
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_full_bench():
     first, line = _run("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                        timeout=900, lines_expected=2)
+    pr = line["per_rank"]        # what a bad N-GPU number is diagnosed from
+    assert len(pr["ms_per_step"]) == 2 and pr["ms_per_step_min"] <= pr["ms_per_step_max"] and pr["rank_of_max"] in (0, 1)
+    assert line["frame"]["gather_ms"] > 0
+    assert "error" not in line["train"], line["train"]          # data-parallel leg: on by default since round 4
     # the headline line leaves before any secondary (collective) leg; the last line repeats it and adds the legs
     assert first["partial"] and "frame" not in first and first["value"] == line["value"] and "partial" not in line
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2
