@@ -15,6 +15,30 @@ constraint) needs 5 wait states before a VMEM instruction reads that SGPR.  Usag
 import re
 import sys
 
+# Every mnemonic an inline-asm statement of this library may contain, with the hazard classes it can take part in and
+# which check below covers them (the compiler pads NOTHING whose producer or consumer sits inside an asm string;
+# cdna_hip_programming.md section 5.7).  An asm mnemonic that is not listed FAILS the audit: a new instruction means a
+# new row here first.
+#   vmem-sgpr   VALU write of an SGPR (v_readfirstlane / v_readlane) -> VMEM reading it: 5 wait states      [checked]
+#   store-data  VMEM store of > 64 bits -> VALU write of its data registers: 2 wait states                  [checked]
+#   load-dest   asm-issued load: destination untouched until a covering s_waitcnt (lgkmcnt / vmcnt)         [checked]
+#   mfma-d      MFMA result (VGPR or AGPR) -> asm instruction reading or writing it: the compiler's MFMA hazard
+#               recognizer does not look inside asm; 18 wait states cover the 16-pass 32x32x2 / 32x32x16 forms [checked]
+#   m0          M0 is written and read inside ONE statement (s_mov m0 / s_nop 0 / global_load_lds); nothing the
+#               compiler emits may touch M0                                                                 [checked]
+#   none        plain VALU on VGPR operands (VALU -> VALU needs no wait states), s_nop, s_waitcnt
+ASM_MNEMONICS = {
+    "s_mov_b32": ("m0",), "s_nop": ("none",), "s_waitcnt": ("none",),
+    "global_load_lds_dwordx4": ("vmem-sgpr", "m0"),
+    "global_store_dwordx4": ("vmem-sgpr", "store-data", "mfma-d"), "global_store_dword": ("vmem-sgpr", "mfma-d"),
+    "global_load_dwordx4": ("vmem-sgpr", "load-dest"), "global_load_dword": ("vmem-sgpr", "load-dest"),
+    "ds_read_b128": ("load-dest",), "ds_read_b32": ("load-dest",),
+    "ds_write_b32": ("mfma-d",), "ds_write_b128": ("mfma-d",),
+    "v_max_f32": ("mfma-d",), "v_min_u32": ("mfma-d",), "v_bfe_i32": ("mfma-d",), "v_fmac_f32": ("mfma-d",),
+    "v_pk_max_i16": ("mfma-d",),
+}
+MFMA_WAIT_STATES = 18
+
 
 def regs(tok):
     m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
@@ -38,6 +62,7 @@ def audit(path):
     pending = []  # [regset, line_no, younger_asm_reads]
     stores = []   # [data regset, line_no, wait states seen since the store]
     sgpr_writes = []   # [sgpr set, line_no, wait states seen since the VALU write]
+    mfma_d = []   # [vgpr set, agpr set, line_no, wait states since]: results of recent MFMAs
     vloads = []   # [dest regset, line_no, younger VMEM operations]: asm-issued global loads nobody has waited for yet
     n_vloads = 0
     n_vmem_s = 0
@@ -56,6 +81,34 @@ def audit(path):
             continue
         op, _, rest = ln.partition(" ")
         toks = [t.strip().rstrip(",") for t in re.split(r"[ ,]+", rest) if t.strip()]
+        # ---- unknown asm mnemonics fail the build; MFMA results must not be touched by asm within the MFMA's shadow
+        if in_asm:
+            base_op = op[:-4] if op.endswith("_e32") or op.endswith("_e64") else op
+            if base_op not in ASM_MNEMONICS:
+                problems += 1
+                print(f"{path}:{no}: `{ln[:70]}`: asm mnemonic `{op}` has no row in ASM_MNEMONICS (scripts/audit_asm_loads.py)")
+            if mfma_d and not op.startswith("s_"):
+                tv, ta = set(), set()
+                for t in toks:
+                    tv |= regs(t)
+                    m_a = re.fullmatch(r"a\[(\d+):(\d+)\]", t) or re.fullmatch(r"a(\d+)", t)
+                    if m_a:
+                        ta |= set(range(int(m_a.group(1)), int(m_a.group(m_a.lastindex)) + 1))
+                for d in mfma_d:
+                    if (tv & d[0]) or (ta & d[1]):
+                        problems += 1
+                        print(f"{path}:{no}: `{ln[:70]}` touches the result of the MFMA at line {d[2]} after {d[3]} wait "
+                              f"state(s) (needs {MFMA_WAIT_STATES}: the compiler pads nothing inside asm)")
+        m_n = re.fullmatch(r"s_nop (\d+)", ln)
+        for d in mfma_d:
+            d[3] += int(m_n.group(1)) + 1 if m_n else (16 if op.startswith("v_mfma") else 1)
+        mfma_d = [d for d in mfma_d if d[3] < MFMA_WAIT_STATES]
+        if op.startswith("v_mfma") and toks:
+            dv, da = regs(toks[0]), set()
+            m_a = re.fullmatch(r"a\[(\d+):(\d+)\]", toks[0])
+            if m_a:
+                da = set(range(int(m_a.group(1)), int(m_a.group(2)) + 1))
+            mfma_d.append([dv, da, no, 0])
         # ---- asm-issued global loads (mlp_layered.hip: B operands, ReLU masks): the compiler believes the destination valid
         # from the moment of issue; nothing may read or write it before a vmcnt wait that covers the load (VMEM returns
         # in order: vmcnt(N) leaves at most the N youngest operations outstanding)

@@ -222,6 +222,24 @@ def grad_digest(net):
     return d
 
 
+class ReluSigns:
+    """The reference's own ReLU decisions, captured with a forward hook on its ONE nn.ReLU module (nerf.py:102-118 calls
+    it ten times: h0..h4, h5..h7, sigma, h9).  Stored as packed bits in the oracle's layout (M, 8 F + F/2 + 1) =
+    [h0 .. h7 | h9 | sigma]: the tests require the kernels' decoded masks to agree with them and
+    then compare gradients on mask-identical fixtures at summation-order tolerance instead of a flip-blind one."""
+
+    def __init__(self, net):
+        self.calls = []
+        self.handle = net.relu_actvn.register_forward_hook(lambda m, i, o: self.calls.append((o.detach() > 0).numpy()))
+
+    def packed(self):
+        self.handle.remove()
+        assert len(self.calls) == 10, len(self.calls)
+        planes = self.calls[:8] + [self.calls[9], self.calls[8][:, None]]
+        bits = np.concatenate(planes, axis=1).astype(np.uint8)
+        return np.packbits(bits.reshape(-1)), np.array(bits.shape, np.int64)
+
+
 # ---------------------------------------------------------------- F5 MLP
 def f5_mlp():
     rng = np.random.RandomState(17)
@@ -234,7 +252,9 @@ def f5_mlp():
     for tag, kw in (("default", dict(seed=1)), ("dense", dict(seed=2, sigma_bias=1.0, sigma_gain=30.0))):
         flat = synth.nerf_flat_params(**kw)
         net = load_ref_net(flat)
+        signs = ReluSigns(net)
         sigma, rgb = net(pe, de)
+        out[tag + "_relu_bits"], out[tag + "_relu_shape"] = signs.packed()
         g_sigma = torch.from_numpy(rng.standard_normal(M).astype(np.float32))
         g_rgb = torch.from_numpy(rng.standard_normal((M, 3)).astype(np.float32))
         (sigma * g_sigma).sum().add((rgb * g_rgb).sum()).backward()
@@ -462,7 +482,9 @@ def f11_net_variants():
         net = ref_nerf.NeRF(ce.out_dim, de_.out_dim, feat)
         net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in
                              synth.split_flat_params(flat, ce.out_dim, de_.out_dim, feat).items()})
+        signs = ReluSigns(net)
         sigma, rgb = net(pe, de)
+        out[tag + "_relu_bits"], out[tag + "_relu_shape"] = signs.packed()
         (sigma * torch.from_numpy(g_sigma)).sum().add((rgb * torch.from_numpy(g_rgb)).sum()).backward()
         out[tag + "_dims"] = np.array([ce.out_dim, de_.out_dim, feat, lp, ld, int(inc)])
         out[tag + "_pe"] = pe.detach().numpy(); out[tag + "_de"] = de.detach().numpy()
@@ -509,7 +531,9 @@ def f12_sh_encoder():
     flat = synth.nerf_flat_params(seed=6, pos_dim=16, view_dir_dim=16, sigma_bias=0.5, sigma_gain=4.0)
     net = ref_nerf.NeRF(16, 16)
     net.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in synth.split_flat_params(flat, 16, 16, 256).items()})
+    signs = ReluSigns(net)
     sigma, rgb = net(enc.encode(x).as_subclass(torch.Tensor), enc.encode(v).as_subclass(torch.Tensor))
+    out["net_relu_bits"], out["net_relu_shape"] = signs.packed()
     g_sigma = rng.standard_normal(M).astype(np.float32); g_rgb = rng.standard_normal((M, 3)).astype(np.float32)
     (sigma * torch.from_numpy(g_sigma)).sum().add((rgb * torch.from_numpy(g_rgb)).sum()).backward()
     out.update(net_sigma=sigma.detach().numpy(), net_rgb=rgb.detach().numpy(), net_g_sigma=g_sigma, net_g_rgb=g_rgb,
