@@ -12,7 +12,7 @@ import torch_nerf.src.renderer.integrators.quadrature_integrator as integrators
 import torch_nerf.src.renderer.ray_samplers as ray_samplers
 from torch_nerf.src.renderer.volume_renderer import VolumeRenderer
 from torch_nerf.src.signal_encoder import SHEncoder
-from torch_nerf.amd import synth
+from torch_nerf.amd import ops, synth
 from helpers import check_grad_digest
 
 pytestmark = pytest.mark.gpu
@@ -109,3 +109,24 @@ def test_render_scene_with_sh_encoders(oracle):
     want_rgb, want_fw = ref(w_before.cpu().numpy(), u1.cpu().numpy(), u2.cpu().numpy(), u3.cpu().numpy())
     np.testing.assert_allclose(f_rgb.cpu().numpy(), want_rgb, rtol=0, atol=1e-5)
     np.testing.assert_allclose(f_w.cpu().numpy(), want_fw, rtol=0, atol=1e-5)
+
+
+def test_sh_encoder_backward_with_strided_input(oracle):
+    """a column slice / transposed view that requires grad -- the reverse kernel must see the same rows the
+    forward encoded (its contiguous fp32 copy), and the gradient must come back in the input's own layout."""
+    rng = np.random.RandomState(9)
+    wide = torch.from_numpy(rng.uniform(-1, 1, (300, 6)).astype(np.float32)).cuda().requires_grad_(True)
+    x = wide[:, 3:6]                                   # strides (6, 1): not contiguous
+    assert not x.is_contiguous()
+    g_out = torch.from_numpy(rng.standard_normal((300, 16)).astype(np.float32)).cuda()
+    enc = ops.ShencFunction.apply(x, 4)
+    (enc * g_out).sum().backward()
+    want = oracle.shenc_backward(wide.detach().cpu().numpy()[:, 3:6].copy(), g_out.cpu().numpy(), 4)
+    got = wide.grad.cpu().numpy()
+    np.testing.assert_allclose(got[:, 3:6], want, rtol=1e-5, atol=1e-6)
+    assert np.all(got[:, :3] == 0)
+    xt = torch.from_numpy(rng.uniform(-1, 1, (3, 200)).astype(np.float32)).cuda().requires_grad_(True)
+    enc = ops.ShencFunction.apply(xt.t(), 4)           # transposed view
+    (enc * g_out[:200]).sum().backward()
+    want = oracle.shenc_backward(xt.detach().cpu().numpy().T.copy(), g_out[:200].cpu().numpy(), 4)
+    np.testing.assert_allclose(xt.grad.cpu().numpy().T, want, rtol=1e-5, atol=1e-6)

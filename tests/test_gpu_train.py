@@ -397,6 +397,68 @@ def test_data_parallel_step_with_a_rank_without_gradients_does_not_hang():
     np.testing.assert_allclose(got[0], want, rtol=0, atol=1e-7)
 
 
+def _ragged_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from torch_nerf.amd.optim import FusedAdam
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nets = _nets(5)
+        params = [p for net in nets for p in net.parameters()]
+        opt = FusedAdam(params, lr=5e-4)
+        for s in range(3):
+            _fake_backward(nets, 11 + s)
+            # ragged shards: rank 1 has holes (fc_3 of both networks), NO rank has a gradient for fc_7.bias
+            for net in nets:
+                net.fc_7.bias.grad = None
+                if rank == 1:
+                    net.fc_3.weight.grad = None
+                    net.fc_3.bias.grad = None
+            opt.step()
+        steps = list(opt._arenas[0].steps)
+        q.put((rank, torch.cat([p.detach().reshape(-1) for p in params]).cpu().numpy(), steps))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_with_ragged_gradient_holes():
+    """ranks whose gradient sets differ take different host paths through FusedAdam.step (a rank with
+    every gradient never reads the reduced has-gradient flags back, a rank with a hole does).  Both must end with
+    identical parameters and identical per-parameter step counts: a parameter steps iff SOME rank holds a gradient
+    for it (what DDP + torch.optim.Adam do), with the mean over ranks of what was contributed."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (v, st) for r, v, st in (q.get(timeout=600) for _ in procs)}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1]
+    # reference: one process, torch.optim.Adam on the rank-averaged gradients (both ranks ran the same _fake_backward)
+    nets = _nets(5)
+    params = [p for net in nets for p in net.parameters()]
+    ropt = torch.optim.Adam(params, lr=5e-4, eps=1e-8)
+    names = [k for net in nets for k, _ in net.named_parameters()]
+    for s in range(3):
+        _fake_backward(nets, 11 + s)
+        for net in nets:
+            net.fc_7.bias.grad = None
+            net.fc_3.weight.grad = net.fc_3.weight.grad * 0.5        # mean of (g, 0)
+            net.fc_3.bias.grad = net.fc_3.bias.grad * 0.5
+        ropt.step()
+    want = torch.cat([p.detach().reshape(-1) for p in params]).cpu().numpy()
+    np.testing.assert_allclose(got[0][0], want, rtol=0, atol=2e-7)
+    assert [st for st, n in zip(got[0][1], names) if n == "fc_7.bias"] == [0, 0]      # never stepped
+    assert all(st == 3 for st, n in zip(got[0][1], names) if n != "fc_7.bias")
+
+
 def test_training_step_is_deterministic():
     """No atomics anywhere on the path: the same two steps twice give bit-identical parameters."""
     assert torch.equal(_two_steps(1), _two_steps(1))

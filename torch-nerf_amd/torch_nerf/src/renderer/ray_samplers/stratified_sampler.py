@@ -78,12 +78,15 @@ class StratifiedSampler(RaySamplerBase):
         torch.linspace on the device, exactly as the reference builds them (stratified_sampler.py:150-162); they are
         remembered per (bounds, count, device) -- every render_scene call of a run asks for the same ones, and the launch
         is 5 us of a 1 ms bf16 render step.  The tensor is read-only for every consumer (kernels take it const)."""
-        key = (float(t_start), float(t_end), int(num_partitions), str(torch.device(device) if not isinstance(device, int)
-                                                                       else torch.device("cuda", device)))
+        dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if dev.type == "cuda" and dev.index is None:       # "cuda" means the CURRENT device: key the cache by its index,
+            dev = torch.device("cuda", torch.cuda.current_device())   # or a later set_device would get the old GPU's tensor
+        key = (float(t_start), float(t_end), int(num_partitions), str(dev))
         edges = self._T_BINS.get(key)
         if edges is None:
             if len(self._T_BINS) > 64:
                 self._T_BINS.clear()
-            edges = torch.linspace(t_start, t_end, num_partitions + 1, device=device)[:-1].contiguous()
+            with torch.inference_mode(False):              # a cached INFERENCE tensor could not be used under autograd later
+                edges = torch.linspace(t_start, t_end, num_partitions + 1, device=dev)[:-1].contiguous()
             self._T_BINS[key] = edges
         return edges, (t_end - t_start) / num_partitions
