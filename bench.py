@@ -449,6 +449,59 @@ def frame_api_leg(renderer, scene_c, scene_f, cam_pose, focal):
     return out
 
 
+def net_variants_leg(device):
+    """The rest of the reference's constructor space NeRF(pos_dim, view_dir_dim, feat_dim) (network/nerf.py:24-63), driver-run
+    (VERDICT r03 item 1): the layered family on a narrow (register-resident kernels) and a wide (plane-parked kernel)
+    network, forward / record forward / backward as fractions of the fp32 MFMA peak on the networks' own algorithmic
+    FLOPs, and the default network's call whose INPUTS require grad (record forward + input-gradient dX chain + dW)."""
+    from torch_nerf.amd import ops, synth
+    M = RAYS * (N_COARSE + N_FINE)          # 786 432: the sample count of the headline's fine pass
+
+    def t(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    out = {"samples": M, "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS}
+    gs, gc = torch.randn(M, device=device), torch.randn(M, 3, device=device)
+    for e_p, e_d, F in ((63, 27, 128), (63, 27, 512)):
+        H2 = F // 2
+        mac = e_p * F + 4 * F * F + (F + e_p) * F + 2 * F * F + F * (F + 1) + (F + e_d) * H2 + 3 * H2
+        net = ops.Net.dims_only(e_p, e_d, F)
+        flat = torch.from_numpy(synth.nerf_flat_params(seed=1, pos_dim=e_p, view_dir_dim=e_d, feat_dim=F)).to(device)
+        pe, de = torch.randn(M, e_p, device=device), torch.randn(M, e_d, device=device)
+        fwd = t(lambda: ops.mlp_layered_forward(flat, pe, de, net))
+        sigma, rgb, rec = ops.mlp_layered_forward(flat, pe, de, net, record=True)
+        rfwd = t(lambda: ops.mlp_layered_forward(flat, pe, de, net, record=True))
+        bwd = t(lambda: ops.mlp_layered_backward(flat, pe, de, net, sigma, rgb, rec, gs, gc))
+        frac = lambda flop, ms: round(flop * M / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+        out[f"nerf_{e_p}_{e_d}_{F}"] = {"forward_ms": fwd, "forward_frac": frac(2 * mac, fwd), "record_forward_ms": rfwd,
+                                        "record_forward_frac": frac(2 * mac, rfwd), "backward_ms": bwd,
+                                        "backward_frac": frac(4 * mac, bwd), "flop_per_sample_forward": 2 * mac}
+        del sigma, rgb, rec
+    # default network, inputs require grad: gradients w.r.t. the encoded inputs out of the fused dX chain
+    e_p, e_d, F, H2 = 63, 27, 256, 128
+    mac = e_p * F + 4 * F * F + (F + e_p) * F + 2 * F * F + F * (F + 1) + (F + e_d) * H2 + 3 * H2
+    ig = 2 * e_p * F + e_d * H2
+    flat = torch.from_numpy(synth.nerf_flat_params(seed=1)).to(device)
+    packed = ops.mlp_pack(flat)
+    pe, de = torch.randn(M, e_p, device=device), torch.randn(M, e_d, device=device)
+    sigma, rgb, saved = ops.mlp_forward(packed, pe, de, True, save=True)
+    fwd = t(lambda: ops.mlp_forward(packed, pe, de, True, save=True))
+    bwd = t(lambda: ops.mlp_backward(packed, flat, pe, de, True, sigma, rgb, saved, gs, gc, want_pos=True, want_dir=True))
+    out["input_gradient_call_63_27_256"] = {
+        "record_forward_ms": fwd, "backward_with_input_grads_ms": bwd,
+        "frac": round((6 * mac + 2 * ig) * M / ((fwd + bwd) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+        "what": "NeRF.forward on pre-encoded inputs that require grad: record forward + dX chain with g_pos / g_view_dir + dW"}
+    return out
+
+
 def runner_loop_leg(device, local_rank, steps, warmup):
     """The per-batch body of the reference's train_one_epoch (runners/train.py:120-218), statement by statement,
     against the drop-in classes -- what an UNMODIFIED runner pays per step: a fresh PerspectiveCamera per batch,
@@ -946,6 +999,7 @@ def main():
                     result["train"]["roofline"]["traffic_detail"] = dict(zip(("forward_record", "dx_chain", "dw_gemms"), parts))
     if rank == 0 and world == 1 and not args.no_stages:
         result["hbm_stages"] = guarded("hbm_stages", lambda: hbm_stages(device))
+        result["net_variants"] = guarded("net_variants", lambda: net_variants_leg(device))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out = guarded("cpu_baseline", lambda: cpu_baseline(flats, focal, pose, device))
         if isinstance(out, tuple):
