@@ -17,9 +17,9 @@ pmc write WRITE_SIZE
 cd $R
 { echo "# rocprofv3 --kernel-trace --stats -- $CMD"; python3 scripts/rocpd_stats.py $(find $OUT/trace -name "*_results.db" | head -1) | head -24; } > gpurun_out/${TAG}_layered_kernel_stats.txt
 { echo "# rocprofv3 --pmc passes (separate runs) of: $CMD"
-  echo "# NeRF(63,27,128): narrow_forward_kernel / narrow_dx_kernel; NeRF(63,27,512): layered_kernel<false> (forward) / <true> (reverse chain);"
+  echo "# NeRF(63,27,128): reg_forward_kernel<2,..> / narrow_dx_kernel; NeRF(63,27,512): layered_kernel<false> (forward) / <true> (reverse chain);"
   echo "# dW of both: mlp_bwd_dw_list_kernel.  FETCH_SIZE / WRITE_SIZE in KiB (raw; FETCH_SIZE tallies 16-B/lane streams at half their bytes)"
-  for p in mfma wait fetch write; do for k in narrow_forward narrow_dx layered_kernel mlp_bwd_dw_list layered_thin; do python3 scripts/rocpd_pmc.py $OUT/$p/${p}_results.db "$k" 2>/dev/null; done; done; } > gpurun_out/${TAG}_pmc_layered.txt
+  for p in mfma wait fetch write; do for k in reg_forward narrow_dx layered_kernel mlp_bwd_dw_list layered_thin; do python3 scripts/rocpd_pmc.py $OUT/$p/${p}_results.db "$k" 2>/dev/null; done; done; } > gpurun_out/${TAG}_pmc_layered.txt
 python3 scripts/layered_time.py 262144 > gpurun_out/${TAG}_layered_family.txt 2>&1
 python3 scripts/layered_time.py 786432 >> gpurun_out/${TAG}_layered_family.txt 2>&1
 cat gpurun_out/${TAG}_layered_family.txt | grep -v amdgpu; head -20 gpurun_out/${TAG}_layered_kernel_stats.txt

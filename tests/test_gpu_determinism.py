@@ -71,7 +71,8 @@ def test_fused_family_record_forward_and_backward_are_bit_reproducible(name, key
                 assert same_bits(x, y), f"{name}: output {k} differs in repetition {rep}"
 
 
-LAYERED_CASES = [("narrow-128", (63, 27, 128)), ("narrow-3-pos-blocks", (75, 27, 100)), ("wide-512", (63, 27, 512)),
+LAYERED_CASES = [("narrow-128", (63, 27, 128)), ("narrow-3-pos-blocks", (75, 27, 100)), ("reg-256-level-12", (75, 27, 256)),
+                 ("wide-512", (63, 27, 512)),
                  ("ragged-160", (40, 40, 160)), ("thin-64", (75, 39, 64))]
 
 

@@ -279,7 +279,7 @@ __device__ __forceinline__ void mma_slots(f32x16 *acc, const f32x16 *b, const ch
 // 32 samples x 256 features fill in the wide kernels): every A fragment feeds 8 MFMAs instead of 4 -- half the LDS
 // reads and half the weight stream per MFMA.  Slot-major chunk as in mma_slots, slot = kb * STRIDE + fb; the k-blocks
 // multiplied are kb = 0 .. NKB-1, the operands of k-block kb are bsel(0, kb) / bsel(1, kb) (references to f32x16).
-template <int NFB, int NKB, int STRIDE, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false, class BSel>
+template <int NFB, int NKB, int STRIDE, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false, int NSB = 2, class BSel>
 __device__ __forceinline__ void mma_slots2(f32x16 *acc0, f32x16 *acc1, BSel bsel, const char *chunk, const int (&offq)[4],
                                            const Pipe *pipe = nullptr) {
     static_assert(NFB <= STRIDE && STRIDE * NKB <= 8, "a chunk holds eight slots");
@@ -299,25 +299,25 @@ __device__ __forceinline__ void mma_slots2(f32x16 *acc0, f32x16 *acc1, BSel bsel
             abuf[g1 & 1] = lds_read_fragment(addr[q1], (kb1 * STRIDE + fb1) * 4096);
         }
         const f32x4 a = abuf[g & 1];
-        const f32x16 &b0 = bsel(0, kb), &b1 = bsel(1, kb);
+        const f32x16 &b0 = bsel(0, kb), &b1 = bsel(NSB - 1, kb);      // (NSB = 1: one sample block, acc1 / b1 unused)
         if (FRESH && kb == 0 && q == 0) {
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             acc0[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0[4 * q + 0], zero, 0, 0, 0);
-            acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[4 * q + 0], zero, 0, 0, 0);
+            if (NSB > 1) acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[4 * q + 0], zero, 0, 0, 0);
         } else {
             acc0[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0[4 * q + 0], acc0[fb], 0, 0, 0);
-            acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[4 * q + 0], acc1[fb], 0, 0, 0);
+            if (NSB > 1) acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[4 * q + 0], acc1[fb], 0, 0, 0);
         }
         acc0[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0[4 * q + 1], acc0[fb], 0, 0, 0);
-        acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1[4 * q + 1], acc1[fb], 0, 0, 0);
+        if (NSB > 1) acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1[4 * q + 1], acc1[fb], 0, 0, 0);
         if (N_PIECES > 0) {   // the next pair's DMA pieces, spread evenly over this chunk's groups
 #pragma unroll
             for (int pp = g * N_PIECES / GROUPS; pp < (g + 1) * N_PIECES / GROUPS; ++pp) pipe->issue_piece(FIRST_PIECE + pp);
         }
         acc0[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0[4 * q + 2], acc0[fb], 0, 0, 0);
-        acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1[4 * q + 2], acc1[fb], 0, 0, 0);
+        if (NSB > 1) acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1[4 * q + 2], acc1[fb], 0, 0, 0);
         acc0[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0[4 * q + 3], acc0[fb], 0, 0, 0);
-        acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1[4 * q + 3], acc1[fb], 0, 0, 0);
+        if (NSB > 1) acc1[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1[4 * q + 3], acc1[fb], 0, 0, 0);
     }
 }
 

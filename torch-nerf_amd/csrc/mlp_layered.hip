@@ -22,6 +22,7 @@
 //
 // The pass programs are pure functions of the widths (fwd_pass / dx_pass, __host__ __device__): the kernels
 // evaluate them on the scalar unit at every pass boundary, the pack kernel evaluates them per pair.
+#include <type_traits>
 #include <vector>
 
 #include "mlp_device.h"
@@ -573,24 +574,26 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// narrow networks (feat_dim 97..128, view_dir_dim <= 32, pos_dim <= 96, e.g. NeRF(63, 27, 128)): register-resident
+// networks whose activations fit the register file: feat_dim 97..128 (NSB = 2) and 225..256 (NSB = 1), view_dir_dim
+// <= 32, pos_dim <= 96 -- e.g. NeRF(63, 27, 128), or NeRF(75..99, 27, 256) = coord_encode_level 12..15, which the fused
+// family (pos_dim <= 64) does not take
 // ---------------------------------------------------------------------------------------------------------------
-// 128 features x 64 samples per wavefront fill the registers that 256 x 32 fill in the fused family: the D fragment
-// of a layer is the B fragment of the next again, nothing is parked -- planes are written only for a backward that
-// will read them (RECORD) -- and every A fragment feeds two sample blocks (mma_slots2).  Same streams, same planes,
-// same dW path as the general kernel above, whose pass programs these kernels walk with everything unrolled:
-//   forward   fc_in 1 pair | fc_1..4 1 each | fc_5 2 | fc_6..8 1 each | fc_9 1           (PB = pos blocks, 1..3)
-//   reverse   fc_9^T 1 | [g_view_dir 1] | fc_8^T .. fc_1^T 1 each | [g_pos 1 (PB <= 2) or 2 (PB = 3)]
-constexpr int NARROW_LDS = RING_SLOTS * CHUNK_BYTES + 8192;   // ring + the constant block (<= 2048 floats)
+// NSB sample blocks x NFB = 8 / NSB feature blocks per wavefront: 128 accumulator + 128 activation registers either way.
+// The D fragment of a layer is the B fragment of the next again, nothing is parked -- planes are written only for a
+// backward that will read them (RECORD) -- and with NSB = 2 every A fragment feeds two sample blocks (mma_slots2: half
+// the LDS reads and half the weight stream per MFMA).  Same streams, same planes, same dW path as the general kernel
+// above, whose pass programs these kernels walk with everything unrolled (PB = position blocks, 1..3):
+//   forward   fc_in | fc_1..4 | fc_5 (pos blocks first) | fc_6..8 | fc_9 (fc_8's output blocks, then the direction)
+//   reverse   fc_9^T | [g_view_dir] | fc_8^T .. fc_1^T | [g_pos: dY0 blocks, then dY5 blocks re-read from their plane]
+constexpr int REG_LDS = RING_SLOTS * CHUNK_BYTES + 16384;   // ring + the constant block (<= 4096 floats)
 
-__host__ __device__ inline bool narrow_ok(const Dims &D) { return D.Fp == 128 && D.Hp == 64 && D.Dp == 32 && D.Pp <= 96; }
+__host__ __device__ inline bool reg_ok(const Dims &D) {
+    return ((D.Fp == 128 && D.Hp == 64) || (D.Fp == 256 && D.Hp == 128)) && D.Dp == 32 && D.Pp <= 96 && D.c_floats() <= 4096;
+}
 
-struct NCtx {
-    const char *lds;
-    const float *cb;
-    int offq[4];
-    int i, h;
-};
+template <int N, class F> __device__ __forceinline__ void static_for(F f) {     // f(integral_constant<0>) .. f(<N-1>)
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
 
 // this lane's 16 registers of block `blk` of a 32-sample tile (the lane's own slots, as save_plane stores them)
 __device__ __forceinline__ f32x16 load_block(const float *tile, int blk, int i, int h) {
@@ -603,20 +606,54 @@ __device__ __forceinline__ f32x16 load_block(const float *tile, int blk, int i, 
     return x;
 }
 
-template <int NB>
-__device__ __forceinline__ void bias_init(f32x16 *acc0, f32x16 *acc1, const float *bias, int h) {
+template <int NSB, int NB>
+__device__ __forceinline__ void bias_init(f32x16 (*acc)[8 / NSB], const float *bias, int h) {
 #pragma unroll
     for (int fb = 0; fb < NB; ++fb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(bias + 32 * fb + 8 * q + 4 * h);
-            acc0[fb][4 * q + 0] = v.x; acc0[fb][4 * q + 1] = v.y; acc0[fb][4 * q + 2] = v.z; acc0[fb][4 * q + 3] = v.w;
-            acc1[fb][4 * q + 0] = v.x; acc1[fb][4 * q + 1] = v.y; acc1[fb][4 * q + 2] = v.z; acc1[fb][4 * q + 3] = v.w;
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) {
+                acc[sb][fb][4 * q + 0] = v.x; acc[sb][fb][4 * q + 1] = v.y; acc[sb][fb][4 * q + 2] = v.z; acc[sb][fb][4 * q + 3] = v.w;
+            }
         }
 }
 
-template <int PB, bool RECORD>
-__global__ __launch_bounds__(256, 1) void narrow_forward_kernel(const WideArgs a) {
+// The k-blocks seq(sb, 0 .. N-1) of one pass against NFBC accumulator blocks: chunks of KPCX k-blocks (slot stride
+// STRIDE), two chunks per pair.  `w0` = the already acquired first pair, or null.  `before(c)` runs in front of chunk c
+// (a hook: the reverse chain re-reads dY5 between the dY0 and the dY5 blocks of g_pos).
+// FRESH: the accumulators start from zero (C = 0 in the first MFMAs).
+template <int NSB, int NFBC, int STRIDE, int KPCX, int N, bool FRESH, bool ACQ_FIRST, class Seq, class Before>
+__device__ __forceinline__ void run_blocks(f32x16 *acc0, f32x16 *acc1, Seq seq, Before before, const char *w0, const char *lds,
+                                           Pipe &pipe, const int (&offq)[4]) {
+    constexpr int CH = (N + KPCX - 1) / KPCX, LAST = N - (CH - 1) * KPCX;   // chunks; k-blocks of the last one
+    const char *w = w0;       // (ACQ_FIRST: the first pair is acquired here; a template flag, not `w0 == nullptr`: no run-time
+                              // branch may sit around an acquire, and LDS address 0 is a valid pointer)
+    // (a plain unrolled loop: every `c` below is a constant after unrolling and the untaken arms disappear; nested
+    // template lambdas here cost the reverse chain ~100 spilled registers)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if (c % 2 == 0 && (c > 0 || ACQ_FIRST)) w = lds + pipe.acquire();
+        before(c);
+        auto b = [&](int sb, int kb) -> const f32x16 & { return seq(sb, c * KPCX + kb); };
+        const char *wc = w + (c % 2) * CHUNK_BYTES;
+        if (c == CH - 1) {
+            if (c == 0) mma_slots2<NFBC, LAST, STRIDE, 0, 16, FRESH, NSB>(acc0, acc1, b, wc, offq, &pipe);
+            else if (c % 2 == 0) mma_slots2<NFBC, LAST, STRIDE, 0, 16, false, NSB>(acc0, acc1, b, wc, offq, &pipe);
+            else mma_slots2<NFBC, LAST, STRIDE, 0, 0, false, NSB>(acc0, acc1, b, wc, offq);
+        } else {
+            if (c == 0) mma_slots2<NFBC, KPCX, STRIDE, 0, 16, FRESH, NSB>(acc0, acc1, b, wc, offq, &pipe);
+            else if (c % 2 == 0) mma_slots2<NFBC, KPCX, STRIDE, 0, 16, false, NSB>(acc0, acc1, b, wc, offq, &pipe);
+            else mma_slots2<NFBC, KPCX, STRIDE, 0, 0, false, NSB>(acc0, acc1, b, wc, offq);
+        }
+        if (c % 2 == 1 || c == CH - 1) pipe.issue_done();
+    }
+}
+
+template <int NSB, int PB, bool RECORD>
+__global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
+    constexpr int NFB = 8 / NSB, HB = NFB / 2, KPC = 8 / NFB, KPC9 = 8 / HB, FP = 32 * NFB, HP = 32 * HB, TILE = 128 * NSB;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -638,123 +675,102 @@ __global__ __launch_bounds__(256, 1) void narrow_forward_kernel(const WideArgs a
     const Dims &D = a.D;
     const int64_t MP = a.MP;
     auto plane = [&](int off) { return a.rec + (int64_t)off * MP; };
+    auto none = [](int) {};
 
-    for (int64_t tile = blockIdx.x; tile < MP / 256; tile += gridDim.x) {
-        const int64_t row0 = tile * 256 + wave * 64;
-        const int64_t m[2] = {row0 + i, row0 + 32 + i};
-        f32x16 pe[2][PB], de[2];
+    for (int64_t tile = blockIdx.x; tile < MP / TILE; tile += gridDim.x) {
+        const int64_t row0 = tile * TILE + wave * (32 * NSB);
+        int64_t m[NSB];
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            const float *pt = plane(D.r_pe()) + (row0 + 32 * sb) * D.Pp;
+        for (int sb = 0; sb < NSB; ++sb) m[sb] = row0 + 32 * sb + i;
+        f32x16 pe[NSB][PB], de[NSB];
+        auto load_pe = [&]() {
 #pragma unroll
-            for (int b = 0; b < PB; ++b) pe[sb][b] = load_block(pt, b, i, h);
-            de[sb] = load_block(plane(D.r_de()) + (row0 + 32 * sb) * 32, 0, i, h);
-        }
-        f32x16 acc[2][4], act[2][4];
+            for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+                for (int b = 0; b < PB; ++b) pe[sb][b] = load_block(plane(D.r_pe()) + (row0 + 32 * sb) * D.Pp, b, i, h);
+        };
+        load_pe();
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) de[sb] = load_block(plane(D.r_de()) + (row0 + 32 * sb) * 32, 0, i, h);
+        f32x16 acc[NSB][NFB], act[NSB][NFB];
 
         // ---- fc_in (nerf.py:102)
         {
             const char *w = lds + pipe.acquire();
-            bias_init<4>(acc[0], acc[1], cb + D.c_bias(0), h);
+            bias_init<NSB, NFB>(acc, cb + D.c_bias(0), h);
             auto P = [&](int sb, int kb) -> const f32x16 & { return pe[sb][kb]; };
-            auto P2 = [&](int sb, int kb) -> const f32x16 & { return pe[sb][PB - 1]; };
-            if constexpr (PB == 1) mma_slots2<4, 1, 4, 0, 16>(acc[0], acc[1], P, w, offq, &pipe);
-            else mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], P, w, offq, &pipe);
-            if constexpr (PB == 3) mma_slots2<4, 1, 4>(acc[0], acc[1], P2, w + CHUNK_BYTES, offq);
-            pipe.issue_done();
+            run_blocks<NSB, NFB, NFB, KPC, PB, false, false>(acc[0], acc[NSB - 1], P, none, w, lds, pipe, offq);
         }
         // ---- fc_1 .. fc_8 (:103-113); skip connection at fc_5, pos FIRST (:108)
-        float sig[2] = {0.0f, 0.0f};
+        float sig[NSB];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) sig[sb] = 0.0f;
         for (int l = 1; l <= 8; ++l) {
             const char *w = lds + pipe.acquire();
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
+            for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
-                for (int fb = 0; fb < 4; ++fb)
+                for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) act[sb][fb][r] = relu1(acc[sb][fb][r]);
             if (RECORD) {
-                save_plane<4, true>(plane(D.r_h(l - 1)), 128, m[0], h, act[0]);
-                save_plane<4, true>(plane(D.r_h(l - 1)), 128, m[1], h, act[1]);
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb) save_plane<NFB, true>(plane(D.r_h(l - 1)), FP, m[sb], h, act[sb]);
             }
             if (l == 8) {   // density row of fc_8
-                sig[0] = half_dot<4>(cb + D.c_w8row(), act[0], h);
-                sig[1] = half_dot<4>(cb + D.c_w8row(), act[1], h);
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb) sig[sb] = half_dot<NFB>(cb + D.c_w8row(), act[sb], h);
             }
-            bias_init<4>(acc[0], acc[1], cb + D.c_bias(l), h);
-            auto A0 = [&](int sb, int kb) -> const f32x16 & { return act[sb][kb]; };
-            auto A1 = [&](int sb, int kb) -> const f32x16 & { return act[sb][1 + kb]; };
-            auto A2 = [&](int sb, int kb) -> const f32x16 & { return act[sb][2 + kb]; };
-            auto A3 = [&](int sb, int kb) -> const f32x16 & { return act[sb][3]; };
-            if (l == 5) {   // k-blocks: pos blocks, then h4's four; two per chunk
-                // (the encoded position comes back from its plane -- L2-hot -- instead of living in 32 PB registers
-                // through fc_1..fc_4: with three blocks that alone spills)
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                    for (int b = 0; b < PB; ++b) pe[sb][b] = load_block(plane(D.r_pe()) + (row0 + 32 * sb) * D.Pp, b, i, h);
-                auto P = [&](int sb, int kb) -> const f32x16 & { return pe[sb][kb]; };
-                if constexpr (PB == 1) {
-                    auto PA = [&](int sb, int kb) -> const f32x16 & { return kb == 0 ? pe[sb][0] : act[sb][0]; };
-                    mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], PA, w, offq, &pipe);
-                    mma_slots2<4, 2, 4>(acc[0], acc[1], A1, w + CHUNK_BYTES, offq);
-                    pipe.issue_done();
-                    w = lds + pipe.acquire();
-                    mma_slots2<4, 1, 4, 0, 16>(acc[0], acc[1], A3, w, offq, &pipe);
-                } else if constexpr (PB == 2) {
-                    mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], P, w, offq, &pipe);
-                    mma_slots2<4, 2, 4>(acc[0], acc[1], A0, w + CHUNK_BYTES, offq);
-                    pipe.issue_done();
-                    w = lds + pipe.acquire();
-                    mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], A2, w, offq, &pipe);
-                } else {
-                    auto PA = [&](int sb, int kb) -> const f32x16 & { return kb == 0 ? pe[sb][PB - 1] : act[sb][0]; };
-                    mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], P, w, offq, &pipe);
-                    mma_slots2<4, 2, 4>(acc[0], acc[1], PA, w + CHUNK_BYTES, offq);
-                    pipe.issue_done();
-                    w = lds + pipe.acquire();
-                    mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], A1, w, offq, &pipe);
-                    mma_slots2<4, 1, 4>(acc[0], acc[1], A3, w + CHUNK_BYTES, offq);
-                }
-                pipe.issue_done();
+            bias_init<NSB, NFB>(acc, cb + D.c_bias(l), h);
+            if (l == 5) {
+                // (the encoded position comes back from its plane -- L2-hot -- instead of living in 16 NSB PB registers
+                // through fc_1..fc_4)
+                load_pe();
+                auto S5 = [&](int sb, int k) -> const f32x16 & { return k < PB ? pe[sb][k < PB ? k : 0] : act[sb][k >= PB ? k - PB : 0]; };
+                run_blocks<NSB, NFB, NFB, KPC, PB + NFB, false, false>(acc[0], acc[NSB - 1], S5, none, w, lds, pipe, offq);
             } else {
-                mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], A0, w, offq, &pipe);
-                mma_slots2<4, 2, 4>(acc[0], acc[1], A2, w + CHUNK_BYTES, offq);
-                pipe.issue_done();
+                auto A = [&](int sb, int k) -> const f32x16 & { return act[sb][k]; };
+                run_blocks<NSB, NFB, NFB, KPC, NFB, false, false>(acc[0], acc[NSB - 1], A, none, w, lds, pipe, offq);
             }
         }
         // ---- fc_9 on cat([x[:, 1:], view_dir]) (:116-118); fc_8 has no ReLU (:113)
-        f32x16 a9[2][2];
+        f32x16 a9[NSB][HB];
         {
             const char *w = lds + pipe.acquire();
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
+            for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
-                for (int fb = 0; fb < 4; ++fb) act[sb][fb] = acc[sb][fb];
+                for (int fb = 0; fb < NFB; ++fb) act[sb][fb] = acc[sb][fb];
             if (RECORD) {
-                save_plane<4, true>(plane(D.r_h(8)), 128, m[0], h, act[0]);
-                save_plane<4, true>(plane(D.r_h(8)), 128, m[1], h, act[1]);
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb) save_plane<NFB, true>(plane(D.r_h(8)), FP, m[sb], h, act[sb]);
             }
-            bias_init<2>(a9[0], a9[1], cb + D.c_bias(9), h);
-            auto Y = [&](int sb, int kb) -> const f32x16 & { return act[sb][kb]; };
-            auto V = [&](int sb, int kb) -> const f32x16 & { return de[sb]; };
-            mma_slots2<2, 4, 2, 0, 16>(a9[0], a9[1], Y, w, offq, &pipe);
-            mma_slots2<2, 1, 2>(a9[0], a9[1], V, w + CHUNK_BYTES, offq);
-            pipe.issue_done();
+#pragma unroll
+            for (int fb = 0; fb < HB; ++fb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(cb + D.c_bias(9) + 32 * fb + 8 * q + 4 * h);
+#pragma unroll
+                    for (int sb = 0; sb < NSB; ++sb) {
+                        a9[sb][fb][4 * q + 0] = v.x; a9[sb][fb][4 * q + 1] = v.y; a9[sb][fb][4 * q + 2] = v.z; a9[sb][fb][4 * q + 3] = v.w;
+                    }
+                }
+            auto S9 = [&](int sb, int k) -> const f32x16 & { return k < NFB ? act[sb][k < NFB ? k : 0] : de[sb]; };
+            run_blocks<NSB, HB, HB, KPC9, NFB + 1, false, false>(a9[0], a9[NSB - 1], S9, none, w, lds, pipe, offq);
         }
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
+        for (int sb = 0; sb < NSB; ++sb) {
 #pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
+            for (int fb = 0; fb < HB; ++fb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a9[sb][fb][r] = relu1(a9[sb][fb][r]);
-            if (RECORD) save_plane<2, true>(plane(D.r_h9()), 64, m[sb], h, a9[sb]);
+            if (RECORD) save_plane<HB, true>(plane(D.r_h9()), HP, m[sb], h, a9[sb]);
             float s = sig[sb] + __shfl_xor(sig[sb], 32, WAVE);
             s = fmaxf(s + cb[D.c_scal()], 0.0f);                      // relu(x[:, 0]) (:115)
             float y[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {                           // sigmoid(fc_out(h9)) (:119)
-                float p = half_dot<2>(cb + D.c_wout() + ch * 64, a9[sb], h);
+                float p = half_dot<HB>(cb + D.c_wout() + ch * HP, a9[sb], h);
                 p += __shfl_xor(p, 32, WAVE);
                 y[ch] = 1.0f / (1.0f + expf(-(p + cb[D.c_scal() + 1 + ch])));
             }
@@ -775,6 +791,11 @@ __device__ __forceinline__ f32x16 masked_by(const f32x16 &v, const f32x16 &act) 
     return x;
 }
 
+// The reverse chain of the narrow networks (NSB = 2): written out for its one geometry -- 128 accumulator + 128
+// activation + 128 ReLU-mask registers leave hipcc no slack, and every generic formulation tried (the run_blocks helper
+// above, run-time FRESH, masks loaded at the seam, ...) spilled 20-150 registers and ran 5-15 % slower.  Networks of
+// 225..256 features take the general reverse chain (layered_kernel<true>: 0.79-0.80 of peak) over the planes the
+// register-resident forward recorded.
 template <int PB, bool IG>
 __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -940,33 +961,40 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+template <int NSB, int PB>
+int launch_reg_fwd(bool record, const WideArgs &a, hipStream_t s) {
+    auto kern = record ? reg_forward_kernel<NSB, PB, true> : reg_forward_kernel<NSB, PB, false>;
+    static nerf::DeviceMask configured[2] = {{0}, {0}};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), REG_LDS, configured[record],
+                                          "nerf_mlp_layered: LDS attribute (register-resident forward)"))
+        return rc;
+    const int64_t ntiles = a.MP / (128 * NSB);
+    const int cus = nerf::device_cus();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(256), REG_LDS, s, a);
+    return nerf::check_launch("nerf_mlp_layered_forward (register-resident)");
+}
+int launch_reg_forward(bool record, const WideArgs &a, hipStream_t s) {
+    const int pb = a.D.Pp / 32;
+    if (a.D.Fp == 128)
+        return pb == 1 ? launch_reg_fwd<2, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<2, 2>(record, a, s) : launch_reg_fwd<2, 3>(record, a, s);
+    return pb == 1 ? launch_reg_fwd<1, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<1, 2>(record, a, s) : launch_reg_fwd<1, 3>(record, a, s);
+}
+
 template <int PB>
-int launch_narrow_pb(bool dx, bool flag, const WideArgs &a, hipStream_t s) {
-    const void *kern = dx ? (flag ? reinterpret_cast<const void *>(narrow_dx_kernel<PB, true>)
-                               : reinterpret_cast<const void *>(narrow_dx_kernel<PB, false>))
-                          : (flag ? reinterpret_cast<const void *>(narrow_forward_kernel<PB, true>)
-                               : reinterpret_cast<const void *>(narrow_forward_kernel<PB, false>));
-    static nerf::DeviceMask configured[4] = {{0}, {0}, {0}, {0}};
-    if (int rc = nerf::ensure_dynamic_lds(kern, NARROW_LDS, configured[2 * dx + flag], "nerf_mlp_layered: LDS attribute (narrow)"))
+int launch_narrow_dx_pb(bool ig, const WideArgs &a, hipStream_t s) {
+    auto kern = ig ? narrow_dx_kernel<PB, true> : narrow_dx_kernel<PB, false>;
+    static nerf::DeviceMask configured[2] = {{0}, {0}};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), REG_LDS, configured[ig],
+                                          "nerf_mlp_layered: LDS attribute (narrow reverse chain)"))
         return rc;
     const int64_t ntiles = a.MP / 256;
     const int cus = nerf::device_cus();
-    const dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));
-    if (dx) {
-        if (flag) hipLaunchKernelGGL((narrow_dx_kernel<PB, true>), grid, dim3(256), NARROW_LDS, s, a);
-        else hipLaunchKernelGGL((narrow_dx_kernel<PB, false>), grid, dim3(256), NARROW_LDS, s, a);
-    } else {
-        if (flag) hipLaunchKernelGGL((narrow_forward_kernel<PB, true>), grid, dim3(256), NARROW_LDS, s, a);
-        else hipLaunchKernelGGL((narrow_forward_kernel<PB, false>), grid, dim3(256), NARROW_LDS, s, a);
-    }
-    return nerf::check_launch(dx ? "nerf_mlp_layered_backward: reverse chain (narrow)" : "nerf_mlp_layered_forward (narrow)");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(256), REG_LDS, s, a);
+    return nerf::check_launch("nerf_mlp_layered_backward: reverse chain (narrow)");
 }
-
-// flag: forward -> record the planes; reverse chain -> input gradients
-int launch_narrow(bool dx, bool flag, const WideArgs &a, hipStream_t s) {
+int launch_narrow_dx(bool ig, const WideArgs &a, hipStream_t s) {
     const int pb = a.D.Pp / 32;
-    return pb == 1 ? launch_narrow_pb<1>(dx, flag, a, s) : pb == 2 ? launch_narrow_pb<2>(dx, flag, a, s)
-                                                                   : launch_narrow_pb<3>(dx, flag, a, s);
+    return pb == 1 ? launch_narrow_dx_pb<1>(ig, a, s) : pb == 2 ? launch_narrow_dx_pb<2>(ig, a, s) : launch_narrow_dx_pb<3>(ig, a, s);
 }
 
 // thin reductions of the reverse pass (vector ALU, HBM-bound: one more read of the h7 and h9 planes):
@@ -1160,8 +1188,8 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
         a.rec = planes; a.grad = nullptr; a.M = rows; a.MP = MP;
         a.n_passes = fwd_num_passes(D); a.n_pairs = pa.n_pairs; a.inputs = 0;
         a.sigma = sigma + r0; a.rgb = rgb + 3 * r0;
-        // narrow networks: register-resident, planes written only when the whole batch is recorded for a backward
-        if (int rc = narrow_ok(D) ? launch_narrow(false, record_rows >= M, a, s) : launch_program(false, a, s)) return rc;
+        // networks that fit the register file: planes written only when the whole batch is recorded for a backward
+        if (int rc = reg_ok(D) ? launch_reg_forward(record_rows >= M, a, s) : launch_program(false, a, s)) return rc;
     }
     return NERF_OK;
 }
@@ -1207,7 +1235,7 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
     a.rec = rec; a.grad = grad; a.M = M; a.MP = MP;
     a.n_passes = dx_num_passes(D, inputs); a.n_pairs = pa.n_pairs; a.inputs = inputs;
     a.sigma_in = sigma; a.rgb_in = rgb; a.g_sigma = g_sigma; a.g_rgb = g_rgb;
-    if (int rc = narrow_ok(D) ? launch_narrow(true, inputs != 0, a, s) : launch_program(true, a, s)) return rc;
+    if (int rc = (reg_ok(D) && D.Fp == 128) ? launch_narrow_dx(inputs != 0, a, s) : launch_program(true, a, s)) return rc;
     if (g_pos) hipLaunchKernelGGL(plane_to_rows_kernel, dim3(grid_for(M * D.E_p)), dim3(256), 0, s,
                                   grad + (int64_t)D.g_gp() * MP, M, D.E_p, D.Pp, g_pos);
     if (g_view_dir) hipLaunchKernelGGL(plane_to_rows_kernel, dim3(grid_for(M * D.E_d)), dim3(256), 0, s,
