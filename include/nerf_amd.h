@@ -157,7 +157,8 @@ int nerf_mlp_backward(const nerf_net_t *net, const void *packed, const float *pa
  * planes between layers (a network of feat_dim 512 does not fit the register file); bias, ReLU / sigmoid and the two
  * torch.cat of nerf.py:108,:116 are fused; every call packs its streams from `params` first.
  *   record_rows >= M : the whole batch is recorded (what nerf_mlp_layered_backward needs)
- *   record_rows <  M : inference, the batch is walked in chunks of record_rows rows through the same buffer
+ *   record_rows <  M : inference, the batch is walked in chunks through the same buffer (record_rows rows each; networks
+ *                      whose activations stay in registers need only the two input planes and take longer chunks)
  * record = nerf_mlp_layered_record_bytes(net, record_rows) bytes (constant block + forward stream + planes).
  * Backward = autograd's result for nerf.py:102-119: g_params (OVERWRITTEN, layout of `params`) and, when non-NULL,
  * g_pos (M,pos_dim) / g_view_dir (M,view_dir_dim), the gradients w.r.t. the encoded inputs.  No atomics: the

@@ -13,7 +13,7 @@ def t(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-NETS = ((63, 27, 256), (75, 27, 256), (63, 27, 128), (75, 39, 64), (63, 27, 512))
+NETS = ((63, 27, 256), (75, 27, 256), (63, 27, 128), (63, 27, 64), (75, 39, 64), (63, 27, 512))
 if len(sys.argv) > 2:   # e.g. "128,512": feat_dims to run (profiling passes)
     NETS = tuple(n for n in NETS if str(n[2]) in sys.argv[2].split(",") or f"{n[0]}x{n[2]}" in sys.argv[2].split(","))
 PEAK = 157.3

@@ -73,7 +73,7 @@ def test_fused_family_record_forward_and_backward_are_bit_reproducible(name, key
 
 LAYERED_CASES = [("narrow-128", (63, 27, 128)), ("narrow-3-pos-blocks", (75, 27, 100)), ("reg-256-level-12", (75, 27, 256)),
                  ("wide-512", (63, 27, 512)),
-                 ("ragged-160", (40, 40, 160)), ("thin-64", (75, 39, 64))]
+                 ("ragged-160", (40, 40, 160)), ("thin-64", (75, 39, 64)), ("reg-64", (63, 27, 64))]
 
 
 @pytest.mark.parametrize("name,dims", LAYERED_CASES, ids=[c[0] for c in LAYERED_CASES])

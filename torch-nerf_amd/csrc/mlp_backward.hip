@@ -293,6 +293,8 @@ struct GemmDesc {
     int col0, valid_cols; // destination column block
     int row0;             // destination row offset (1 for fc_8: row 0 is the density row)
     int valid_rows;       // rows of the window that exist in the destination (a_width for the fused family)
+    int a_split;          // 1 | 2 | 4: the dY window is a_width / a_split wide and the tile's k-steps are split between
+                          // a_split groups of wavefronts, whose partial tiles the reducer folds (narrow layers)
 };
 struct GemmTable {
     GemmDesc g[MAX_GEMMS];
@@ -323,13 +325,8 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned lds_addr, int imm_offset
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 3 || N == 5 || N == 6 || N == 9 || N == 10, "add the immediate below");
-    if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-    if (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    if (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    if (N == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-    if (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(N) : "memory");
 }
 
 // DENSITY (the fc_8 item, X = h7): the density row of fc_8 rides along on the vector ALU --
@@ -348,24 +345,36 @@ __device__ __forceinline__ void wait_vmcnt() {
 // operand; the three colour gradients come from the [sample][4] GY plane the dX chain wrote, through a 512-byte LDS
 // row filled one tile ahead by wave 0.  Wave w takes features 32 w .. 32 w + 31: one ds_read_b32 + one ds_read_b128 +
 // three v_fmac per k-step.  (Rounds 1-2a summed it in a separate HBM-bound kernel: 0.2 ms per step.)
-template <int NA, int KB, int DWAVE = -1, int FWAVE = -1>   // DWAVE / FWAVE >= 0: side job, compiled for that wave
+// ASPLIT > 1 (layers narrower than 128 outputs, NA = 1): the dY window is 128 / ASPLIT wide; wave w takes row block
+// w % (4 / ASPLIT) and the k-steps (sample pairs) of group w / (4 / ASPLIT) -- every wavefront does useful MFMAs and the
+// dY tile is fetched at its own width (a 64-wide layer as a 128-wide window cost twice the MFMAs and 1.5 x the bytes).
+// The groups' partial tiles land in the row blocks of the usual [128][XW] partial; reduce_item folds them.  These
+// items are HBM-bound (F / 4 FLOP per byte): more, smaller stages keep ~64 KiB of tiles in flight per CU.
+template <int NA, int KB, int DWAVE = -1, int FWAVE = -1, int ASPLIT = 1>   // DWAVE / FWAVE >= 0: side job, compiled for that wave
 __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0, int64_t t1,
                                         const float *__restrict__ saved, const float *__restrict__ dy,
                                         float *__restrict__ partial, int64_t MP, char *lds, int tid, int lane,
                                         int wave) {
     constexpr int AW = 128 * NA;  // a_width: each of the 4 waves owns 32*NA rows
     constexpr int XW = 32 * KB;
-    constexpr int A_PIECES = 32 * AW * 4 / 1024 / 4;  // 1-KiB DMA pieces per wave
+    constexpr int AE = AW / ASPLIT;                    // width of the dY window in memory
+    constexpr int RB = 4 / ASPLIT, NS = 16 / ASPLIT;   // row blocks (ASPLIT > 1) and k-steps per wave and tile
+    static_assert(ASPLIT == 1 || (NA == 1 && DWAVE < 0 && FWAVE < 0), "split-k serves the plain narrow items");
+    constexpr int A_PIECES = 32 * AE * 4 / 1024 / 4;  // 1-KiB DMA pieces per wave
     constexpr int X_PIECES = 32 * XW * 4 / 1024 / 4;  // per wave (X tile = 4 | 8 | 32 pieces)
     constexpr bool FCOUT = FWAVE >= 0;
     constexpr int H9_PIECES = FCOUT ? 32 * HALF * 4 / 1024 / 4 : 0;   // per wave: the 16-KiB h9 tile
-    constexpr int A_BYTES = 32 * AW * 4, X_BYTES = 32 * XW * 4, H9_BYTES = FCOUT ? 32 * HALF * 4 : 0;
+    constexpr int A_BYTES = 32 * AE * 4, X_BYTES = 32 * XW * 4, H9_BYTES = FCOUT ? 32 * HALF * 4 : 0;
     constexpr int STAGE_BYTES = A_BYTES + X_BYTES + H9_BYTES;
     // thin X tiles finish their MFMAs faster than one DMA round trip: keep two tiles in flight
-    constexpr int NSTAGE = (KB <= 2) ? 3 : 2;
+    constexpr int NSTAGE = ASPLIT > 1 ? (KB <= 2 ? 6 : KB == 4 ? 4 : 3) : (KB <= 2) ? 3 : 2;
     static_assert(NSTAGE * STAGE_BYTES <= DW_LDS_BYTES, "stage ring exceeds the LDS allocation");
     static_assert(A_PIECES + X_PIECES + H9_PIECES <= 16, "one DMA piece per k-step");
     constexpr int PER_WAVE = A_PIECES + X_PIECES + H9_PIECES;  // DMA instructions per wave per tile
+    constexpr int PPS = (PER_WAVE + NS - 1) / NS;              // ... issued per k-step
+    static_assert((NSTAGE - 2) * PER_WAVE < 64, "counted wait");
+    const int rb = ASPLIT > 1 ? wave % RB : wave, kgrp = ASPLIT > 1 ? wave / RB : 0;   // wave-uniform
+    const unsigned k_off = (unsigned)(64 * NS * kgrp);         // byte offset of this group's first k-step in a fragment row
     const int i = lane & 31, h = lane >> 5;
     const int frag_base = (i >> 3) * 256 + 4 * ((2 * h + ((i >> 2) & 1)) ^ (2 * ((i >> 3) & 1))) + (i & 3);
     const int frag_swing = 16 * (i >> 4);
@@ -455,10 +464,10 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
         // cover the LDS latency) with the feature block and the k-step in the instruction's 16-bit offset:
         // left to hipcc they become ds_read2_b32 with an address add each, all at the top of the loop body.
         const unsigned stage = lds_base + (unsigned)(buf * STAGE_BYTES);
-        const unsigned a_addr[2] = {stage + 4u * (unsigned)(wave * NA * 1024 + frag_base + frag_swing),
-                                    stage + 4u * (unsigned)(wave * NA * 1024 + frag_base - frag_swing)};
-        const unsigned x_addr[2] = {stage + (unsigned)A_BYTES + 4u * (unsigned)(frag_base + frag_swing),
-                                    stage + (unsigned)A_BYTES + 4u * (unsigned)(frag_base - frag_swing)};
+        const unsigned a_addr[2] = {stage + k_off + 4u * (unsigned)(rb * NA * 1024 + frag_base + frag_swing),
+                                    stage + k_off + 4u * (unsigned)(rb * NA * 1024 + frag_base - frag_swing)};
+        const unsigned x_addr[2] = {stage + k_off + (unsigned)A_BYTES + 4u * (unsigned)(frag_base + frag_swing),
+                                    stage + k_off + (unsigned)A_BYTES + 4u * (unsigned)(frag_base - frag_swing)};
         if (DENSITY && DWAVE == 0) {
             // behind the tile-top vmcnt(0) the values of tile t + 1 have landed: into the row nobody reads during
             // tile t (readers of row (t+1)&1 = row (t-1)&1 passed this tile's barrier); then request tile t + 2
@@ -493,10 +502,12 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
         // dW += dY^T X over the 32 samples of the tile: 16 k-steps of 2 samples.  The A fragments
         // (dY values) double as the bias-gradient summands: db[n] = sum over samples of dY[m][n].
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < NS; ++s) {
             lds_fragments_ready();   // k-step s has landed
-            if (s + 1 < 16) DW_FETCH(s + 1)
-            if (s < PER_WAVE) issue_piece(tn, nbuf, s);
+            if (s + 1 < NS) DW_FETCH(s + 1)
+#pragma unroll
+            for (int p = 0; p < PPS; ++p)
+                if (s * PPS + p < PER_WAVE) issue_piece(tn, nbuf, s * PPS + p);
 #pragma unroll
             for (int nb = 0; nb < NA; ++nb) {
                 bsum[nb] += a[s & 1][nb];
@@ -608,9 +619,17 @@ __device__ __forceinline__ void dw_main(const GemmDesc *items, int n_items, int6
             else dw_body<1, 8, -1, 3>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         } else if (g.a_width == 256 && g.x_width == 256) dw_body<2, 8>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 256 && g.x_width == 64) dw_body<2, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
-        else if (g.a_width == 128 && g.x_width == 256) dw_body<1, 8>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
-        else if (g.a_width == 128 && g.x_width == 32) dw_body<1, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_width == 128 && g.x_width == 256 && g.a_split <= 1) dw_body<1, 8>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_width == 128 && g.x_width == 32 && g.a_split <= 1) dw_body<1, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
 #ifndef NERF_DW_FUSED_SHAPES_ONLY   // the other window shapes of the layered family
+        else if (g.a_split == 2 && g.x_width == 256) dw_body<1, 8, -1, -1, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_split == 2 && g.x_width == 128) dw_body<1, 4, -1, -1, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_split == 2 && g.x_width == 64) dw_body<1, 2, -1, -1, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_split == 2) dw_body<1, 1, -1, -1, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_split == 4 && g.x_width == 256) dw_body<1, 8, -1, -1, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_split == 4 && g.x_width == 128) dw_body<1, 4, -1, -1, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_split == 4 && g.x_width == 64) dw_body<1, 2, -1, -1, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (g.a_split == 4) dw_body<1, 1, -1, -1, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 256 && g.x_width == 128) dw_body<2, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 256 && g.x_width == 32) dw_body<2, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 128 && g.x_width == 128) dw_body<1, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
@@ -699,6 +718,21 @@ __device__ __forceinline__ void reduce_item(const GemmDesc &g, const float *__re
         // slices are added in index order (bit-reproducible); the loads of four slices are issued together so that the
         // walk is not one dependent HBM round trip per slice
         float s = 0.0f;
+        if (g.a_split > 1) {   // the k-groups of a narrow item sit a_width / a_split rows apart (rows, or bias entries)
+            const int64_t fold = (int64_t)(g.a_width / g.a_split) * (e < tile ? g.x_width : 1);
+            int sl = 0;
+            for (; sl + 2 <= g.num_slices; sl += 2) {   // (loads of two slices issued together, added in index order)
+                float p[2][4];
+                for (int u = 0; u < 2; ++u)
+                    for (int f = 0; f < 4; ++f) p[u][f] = f < g.a_split ? base[(int64_t)(sl + u) * stride + src + f * fold] : 0.0f;
+                for (int u = 0; u < 2; ++u)
+                    for (int f = 0; f < g.a_split; ++f) s += p[u][f];
+            }
+            for (; sl < g.num_slices; ++sl)
+                for (int f = 0; f < g.a_split; ++f) s += base[(int64_t)sl * stride + src + f * fold];
+            g_params[dst] = s;
+            continue;
+        }
         int sl = 0;
         for (; sl + 4 <= g.num_slices; sl += 4) {
             const float p0 = base[(int64_t)sl * stride + src], p1 = base[(int64_t)(sl + 1) * stride + src];
@@ -730,7 +764,7 @@ Plan make_plan(const Net &net, int64_t M, int cus, const float *saved, const flo
                    int row0, int flags) {
         GemmDesc &g = T.g[n++];
         g.a_src = reinterpret_cast<const char *>(dy + a_off); g.x_src = reinterpret_cast<const char *>(saved + x_off);
-        g.a_stride = 128 * (int64_t)a_width; g.x_stride = 128 * (int64_t)x_width; g.valid_rows = a_width;
+        g.a_stride = 128 * (int64_t)a_width; g.x_stride = 128 * (int64_t)x_width; g.valid_rows = a_width; g.a_split = 1;
         g.a_width = a_width; g.x_width = x_width;
         g.flags = flags; g.in_features = net.layer_in(layer); g.col0 = col0; g.valid_cols = valid_cols; g.row0 = row0;
         g.w_off = net.w_offset(layer); g.b_off = net.b_offset(layer);
@@ -827,6 +861,7 @@ int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int
         const int NA = it.a_blocks > 4 ? 2 : 1;
         const int KB = it.x_blocks > 4 ? 8 : it.x_blocks > 2 ? 4 : it.x_blocks > 1 ? 2 : 1;
         g.a_width = 128 * NA; g.x_width = 32 * KB;
+        g.a_split = it.a_blocks <= 1 ? 4 : it.a_blocks <= 2 ? 2 : 1;
         // (a window wider than what is left of its plane runs on into the next tile's first blocks: finite values in
         // rows / columns the reduction never reads)
         g.a_src = reinterpret_cast<const char *>(it.a_plane + (int64_t)it.a_fb0 * 1024);
@@ -839,6 +874,10 @@ int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int
         // relative tile times by shape (measured for the fused family's four shapes, mlp_backward.hip:make_plan)
         const int nk = NA * KB;
         g.cost = nk == 16 ? 7350 : (NA == 1 && KB == 8) ? 3770 : (NA == 2 && KB == 2) ? 2010 : nk == 1 ? 935 : 450 * nk + 150;
+        if (g.a_split > 1) {   // MFMA time of a wave's share, or the tile's bytes at the CU's share of HBM (~11 B / clock)
+            const int mfma = 450 * KB / g.a_split + 150, hbm = 5 * (128 / g.a_split + 32 * KB);
+            g.cost = mfma > hbm ? mfma : hbm;
+        }
         g.unit_off = units;
         units += tiles * g.cost;
     }

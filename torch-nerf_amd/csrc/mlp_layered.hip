@@ -233,8 +233,10 @@ __global__ void layered_pack_consts(const Dims D, const float *__restrict__ P, f
 }
 
 __global__ void layered_pack_stream(const PackArgs a, float *__restrict__ out) {
-    // one workgroup per pair (grid-stride): find the pass that owns it (scalar walk, <= ~50 passes)
-    for (int pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x) {
+    // one workgroup per 4-KiB slot (grid-stride; 16 slots per pair): find the pass that owns the pair (scalar walk,
+    // <= ~50 passes) -- a narrow network has a dozen pairs, and one workgroup per pair left the chip idle for 65 us
+    for (int unit = blockIdx.x; unit < a.n_pairs * 16; unit += gridDim.x) {
+        const int pair = unit >> 4;
         int idx = 0, first = 0;
         Pass P = a.dx ? dx_pass(a.D, a.inputs, 0) : fwd_pass(a.D, 0);
         while (first + P.pairs() <= pair) {
@@ -243,7 +245,7 @@ __global__ void layered_pack_stream(const PackArgs a, float *__restrict__ out) {
         }
         const int kpc = 8 / P.nfb, total_kb = P.kb0 + P.kb1;
         float *dst = out + (int64_t)pair * (PAIR_BYTES / 4);
-        for (int e = threadIdx.x; e < PAIR_BYTES / 4; e += blockDim.x) {
+        for (int e = (unit & 15) * 1024 + threadIdx.x; e < (unit & 15) * 1024 + 1024; e += blockDim.x) {
             const int b = e * 4;                       // byte offset inside the pair
             const int chunk = b >> 15, slot = (b >> 12) & 7, in_slot = b & 4095;
             const int i = in_slot >> 7;                // row of the 32-row block
@@ -277,18 +279,36 @@ int stream_pairs(const Dims &D, int dx, int inputs) {
 // ---------------------------------------------------------------------------------------------------------------
 // rows <-> planes
 // ---------------------------------------------------------------------------------------------------------------
-// plane[m][k] = k < E ? rows[m][k] : 0 for m < M, 0 for the padded rows (TF layout)
-__global__ void rows_to_plane_kernel(const float *__restrict__ rows, int64_t M, int64_t MP, int E, int W,
-                                     float *__restrict__ plane) {
-    const int64_t total = MP * W;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        // e walks the plane in MEMORY order (coalesced stores): invert tf_offset
-        const int64_t tile = e / (32 * W);
-        const int r = (int)(e - tile * 32 * W);
-        const int slot = r >> 8, unit = ((r & 255) >> 2) ^ (2 * (slot & 3)), el = r & 3;
-        const int64_t m = tile * 32 + (unit >> 1);
-        const int k = 32 * (slot >> 2) + 8 * (slot & 3) + 4 * (unit & 1) + el;
-        plane[e] = (m < M && k < E) ? rows[m * E + k] : 0.0f;
+// plane[m][k] = k < E ? rows[m][k] : 0 for m < M, 0 for the padded rows (TF layout).  One workgroup per 32-sample tile
+// (grid-stride), 128 columns at a time through LDS: the rows of a tile are one contiguous run of the input (read
+// coalesced), the 16 slots of 128 columns one contiguous 16 KiB of the plane (written as 16-byte units in memory
+// order, inverting tf_offset).  (The per-element version moved 2 TB/s.)
+__global__ __launch_bounds__(256) void rows_to_plane_kernel(const float *__restrict__ rows, int64_t M, int64_t MP, int E, int W,
+                                                            float *__restrict__ plane) {
+    __shared__ float t[32 * 129];
+    for (int64_t tile = blockIdx.x; tile < MP / 32; tile += gridDim.x) {
+        for (int kc = 0; kc < W; kc += 128) {
+            const int cw = E - kc < 128 ? (E - kc > 0 ? E - kc : 0) : 128;      // valid columns of this chunk
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < 32 * cw; idx += 256) {
+                const int r = idx / cw, c = idx - r * cw;
+                const int64_t m = tile * 32 + r;
+                t[r * 129 + c] = m < M ? rows[m * E + kc + c] : 0.0f;
+            }
+            __syncthreads();
+            const int wc = W - kc < 128 ? W - kc : 128;                         // plane columns of this chunk
+            for (int u = threadIdx.x; u < wc * 8; u += 256) {                   // 16-byte units: 64 per 256-float slot
+                const int slot = kc / 8 + (u >> 6), w = u & 63;
+                const int unit = w ^ (2 * (slot & 3));
+                const int r = unit >> 1, k = 32 * (slot >> 2) + 8 * (slot & 3) + 4 * (unit & 1) - kc;
+                f32x4 v;
+                v.x = k + 0 < cw ? t[r * 129 + k + 0] : 0.0f;
+                v.y = k + 1 < cw ? t[r * 129 + k + 1] : 0.0f;
+                v.z = k + 2 < cw ? t[r * 129 + k + 2] : 0.0f;
+                v.w = k + 3 < cw ? t[r * 129 + k + 3] : 0.0f;
+                *reinterpret_cast<f32x4 *>(plane + tile * 32 * W + (int64_t)slot * 256 + 4 * w) = v;
+            }
+        }
     }
 }
 __global__ void plane_to_rows_kernel(const float *__restrict__ plane, int64_t M, int E, int W, float *__restrict__ rows) {
@@ -588,7 +608,8 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
 constexpr int REG_LDS = RING_SLOTS * CHUNK_BYTES + 16384;   // ring + the constant block (<= 4096 floats)
 
 __host__ __device__ inline bool reg_ok(const Dims &D) {
-    return ((D.Fp == 128 && D.Hp == 64) || (D.Fp == 256 && D.Hp == 128)) && D.Dp == 32 && D.Pp <= 96 && D.c_floats() <= 4096;
+    return ((D.Fp == 64 && D.Hp == 32) || (D.Fp == 128 && D.Hp == 64) || (D.Fp == 256 && D.Hp == 128)) && D.Dp == 32 &&
+           D.Pp <= 96 && D.c_floats() <= 4096;
 }
 
 template <int N, class F> __device__ __forceinline__ void static_for(F f) {     // f(integral_constant<0>) .. f(<N-1>)
@@ -606,8 +627,8 @@ __device__ __forceinline__ f32x16 load_block(const float *tile, int blk, int i, 
     return x;
 }
 
-template <int NSB, int NB>
-__device__ __forceinline__ void bias_init(f32x16 (*acc)[8 / NSB], const float *bias, int h) {
+template <int NSB, int NFB, int NB>
+__device__ __forceinline__ void bias_init(f32x16 (*acc)[NFB], const float *bias, int h) {
 #pragma unroll
     for (int fb = 0; fb < NB; ++fb)
 #pragma unroll
@@ -651,9 +672,12 @@ __device__ __forceinline__ void run_blocks(f32x16 *acc0, f32x16 *acc1, Seq seq, 
     }
 }
 
-template <int NSB, int PB, bool RECORD>
+// (NSB sample blocks, NFB feature blocks) per wavefront: (1, 8) = feat_dim 225..256, (2, 4) = 97..128, (2, 2) = 33..64
+template <int NSB, int NFB, int PB, bool RECORD>
 __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
-    constexpr int NFB = 8 / NSB, HB = NFB / 2, KPC = 8 / NFB, KPC9 = 8 / HB, FP = 32 * NFB, HP = 32 * HB, TILE = 128 * NSB;
+    // fc_9's pass is packed with at least two accumulator blocks per k-block (pass_nfb)
+    constexpr int HB = NFB / 2, KPC = 8 / NFB, S9 = HB < 2 ? 2 : HB, KPC9 = 8 / S9, FP = 32 * NFB, HP = 32 * HB, TILE = 128 * NSB;
+    static_assert(NSB * NFB <= 8 && NFB >= 2, "register budget");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -697,7 +721,7 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
         // ---- fc_in (nerf.py:102)
         {
             const char *w = lds + pipe.acquire();
-            bias_init<NSB, NFB>(acc, cb + D.c_bias(0), h);
+            bias_init<NSB, NFB, NFB>(acc, cb + D.c_bias(0), h);
             auto P = [&](int sb, int kb) -> const f32x16 & { return pe[sb][kb]; };
             run_blocks<NSB, NFB, NFB, KPC, PB, false, false>(acc[0], acc[NSB - 1], P, none, w, lds, pipe, offq);
         }
@@ -721,7 +745,7 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) sig[sb] = half_dot<NFB>(cb + D.c_w8row(), act[sb], h);
             }
-            bias_init<NSB, NFB>(acc, cb + D.c_bias(l), h);
+            bias_init<NSB, NFB, NFB>(acc, cb + D.c_bias(l), h);
             if (l == 5) {
                 // (the encoded position comes back from its plane -- L2-hot -- instead of living in 16 NSB PB registers
                 // through fc_1..fc_4)
@@ -755,8 +779,8 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
                         a9[sb][fb][4 * q + 0] = v.x; a9[sb][fb][4 * q + 1] = v.y; a9[sb][fb][4 * q + 2] = v.z; a9[sb][fb][4 * q + 3] = v.w;
                     }
                 }
-            auto S9 = [&](int sb, int k) -> const f32x16 & { return k < NFB ? act[sb][k < NFB ? k : 0] : de[sb]; };
-            run_blocks<NSB, HB, HB, KPC9, NFB + 1, false, false>(a9[0], a9[NSB - 1], S9, none, w, lds, pipe, offq);
+            auto Cat9 = [&](int sb, int k) -> const f32x16 & { return k < NFB ? act[sb][k < NFB ? k : 0] : de[sb]; };
+            run_blocks<NSB, HB, S9, KPC9, NFB + 1, false, false>(a9[0], a9[NSB - 1], Cat9, none, w, lds, pipe, offq);
         }
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
@@ -796,8 +820,10 @@ __device__ __forceinline__ f32x16 masked_by(const f32x16 &v, const f32x16 &act) 
 // above, run-time FRESH, masks loaded at the seam, ...) spilled 20-150 registers and ran 5-15 % slower.  Networks of
 // 225..256 features take the general reverse chain (layered_kernel<true>: 0.79-0.80 of peak) over the planes the
 // register-resident forward recorded.
-template <int PB, bool IG>
+template <int NFB, int PB, bool IG>
 __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
+    constexpr int HB = NFB / 2, FP = 32 * NFB, HP = 32 * HB;   // NFB = 4: feat_dim 97..128; NFB = 2: 33..64
+    static_assert(NFB == 4 || NFB == 2, "two sample blocks x NFB feature blocks");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -826,7 +852,7 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
         const int64_t m[2] = {row0 + i, row0 + 32 + i};
         // ---- heads (nerf.py:115, :119) and dY9 = (W_out^T d y10) . [h9 > 0]
         float dsig[2];
-        f32x16 d9[2][2];
+        f32x16 d9[2][HB];
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
             const bool valid = m[sb] < a.M;
@@ -843,36 +869,36 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
                 *reinterpret_cast<f32x4 *>(gplane(D.g_gy()) + 4 * m[sb]) = g4;
                 gplane(D.g_dsig())[m[sb]] = dsig[sb];
             }
-            const float *h9t = rplane(D.r_h9()) + (row0 + 32 * sb) * 64;
+            const float *h9t = rplane(D.r_h9()) + (row0 + 32 * sb) * HP;
 #pragma unroll
-            for (int fb = 0; fb < 2; ++fb) {
+            for (int fb = 0; fb < HB; ++fb) {
                 const f32x16 hv = load_block(h9t, fb, i, h);
                 f32x16 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int k0 = 32 * fb + 8 * q + 4 * h;
                     const f32x4 w0 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + k0);
-                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + 64 + k0);
-                    const f32x4 w2 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + 128 + k0);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + HP + k0);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + 2 * HP + k0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[4 * q + j] = fmaf(w2[j], gy[2], fmaf(w1[j], gy[1], w0[j] * gy[0]));
                 }
                 d9[sb][fb] = masked_by(v, hv);
             }
-            save_plane<2, true>(gplane(D.g_dy9()), 64, m[sb], h, d9[sb]);
+            save_plane<HB, true>(gplane(D.g_dy9()), HP, m[sb], h, d9[sb]);
         }
-        f32x16 acc[2][4], act[2][4], mk[2][4];
+        f32x16 acc[2][NFB], act[2][NFB], mk[2][NFB];
         auto D9 = [&](int sb, int kb) -> const f32x16 & { return d9[sb][kb]; };
         // ---- d y8[1:] = W9[:, :F]^T dY9
         {
             const char *w = lds + pipe.acquire();
-            mma_slots2<4, 2, 4, 0, 16, true>(acc[0], acc[1], D9, w, offq, &pipe);
+            mma_slots2<NFB, HB, NFB, 0, 16, true>(acc[0], acc[1], D9, w, offq, &pipe);
             pipe.issue_done();
         }
         if (IG) {   // g_view_dir = W9[:, F:]^T dY9 (nerf.py:116)
             const char *w = lds + pipe.acquire();
             f32x16 gd[2];
-            mma_slots2<1, 2, 2, 0, 16, true>(&gd[0], &gd[1], D9, w, offq, &pipe);
+            mma_slots2<1, HB, 2, 0, 16, true>(&gd[0], &gd[1], D9, w, offq, &pipe);
             pipe.issue_done();
             save_plane<1, true>(gplane(D.g_gd()), 32, m[0], h, &gd[0]);
             save_plane<1, true>(gplane(D.g_gd()), 32, m[1], h, &gd[1]);
@@ -881,7 +907,7 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-            for (int fb = 0; fb < 4; ++fb) mk[sb][fb] = load_block(rplane(D.r_h(7)) + (row0 + 32 * sb) * 128, fb, i, h);
+            for (int fb = 0; fb < NFB; ++fb) mk[sb][fb] = load_block(rplane(D.r_h(7)) + (row0 + 32 * sb) * FP, fb, i, h);
         __builtin_amdgcn_sched_barrier(0);
         // ---- l = 8 .. 1: dY(l-1) = (W_l^T dY(l)) . [h(l-1) > 0]; the accumulators entering stage l hold dY(l) unmasked
         for (int l = 8; l >= 1; --l) {
@@ -889,66 +915,78 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                for (int fb = 0; fb < 4; ++fb) act[sb][fb] = l == 8 ? acc[sb][fb] : masked_by(acc[sb][fb], mk[sb][fb]);
+                for (int fb = 0; fb < NFB; ++fb) act[sb][fb] = l == 8 ? acc[sb][fb] : masked_by(acc[sb][fb], mk[sb][fb]);
             if (l < 8) {   // masks of the next seam: h(l-1)
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                    for (int fb = 0; fb < 4; ++fb)
-                        mk[sb][fb] = load_block(rplane(D.r_h(l - 1)) + (row0 + 32 * sb) * 128, fb, i, h);
+                    for (int fb = 0; fb < NFB; ++fb)
+                        mk[sb][fb] = load_block(rplane(D.r_h(l - 1)) + (row0 + 32 * sb) * FP, fb, i, h);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            save_plane<4, true>(gplane(D.g_dy(l)), 128, m[0], h, act[0]);
-            save_plane<4, true>(gplane(D.g_dy(l)), 128, m[1], h, act[1]);
+            save_plane<NFB, true>(gplane(D.g_dy(l)), FP, m[0], h, act[0]);
+            save_plane<NFB, true>(gplane(D.g_dy(l)), FP, m[1], h, act[1]);
             auto A0 = [&](int sb, int kb) -> const f32x16 & { return act[sb][kb]; };
-            auto A2 = [&](int sb, int kb) -> const f32x16 & { return act[sb][2 + kb]; };
+            auto A2 = [&](int sb, int kb) -> const f32x16 & { return act[sb][(2 + kb) % NFB]; };
             if (l == 8) {   // + W8[0, :] dsigma' (the density row)
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                    for (int fb = 0; fb < 4; ++fb)
+                    for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 wv = *reinterpret_cast<const f32x4 *>(cb + D.c_w8row() + 32 * fb + 8 * q + 4 * h);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[sb][fb][4 * q + j] = wv[j] * dsig[sb];
                         }
-                mma_slots2<4, 2, 4, 0, 16>(acc[0], acc[1], A0, w, offq, &pipe);
+                mma_slots2<NFB, 2, NFB, 0, 16>(acc[0], acc[1], A0, w, offq, &pipe);
             } else {
-                mma_slots2<4, 2, 4, 0, 16, true>(acc[0], acc[1], A0, w, offq, &pipe);
+                mma_slots2<NFB, 2, NFB, 0, 16, true>(acc[0], acc[1], A0, w, offq, &pipe);
             }
-            mma_slots2<4, 2, 4>(acc[0], acc[1], A2, w + CHUNK_BYTES, offq);
+            // (NFB = 2: the layer's two k-blocks are the first half of the pair's first chunk)
+            if constexpr (NFB == 4) mma_slots2<4, 2, 4>(acc[0], acc[1], A2, w + CHUNK_BYTES, offq);
             pipe.issue_done();
         }
         // ---- dY0
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
 #pragma unroll
-            for (int fb = 0; fb < 4; ++fb) act[sb][fb] = masked_by(acc[sb][fb], mk[sb][fb]);
-            save_plane<4, true>(gplane(D.g_dy(0)), 128, m[sb], h, act[sb]);
+            for (int fb = 0; fb < NFB; ++fb) act[sb][fb] = masked_by(acc[sb][fb], mk[sb][fb]);
+            save_plane<NFB, true>(gplane(D.g_dy(0)), FP, m[sb], h, act[sb]);
         }
         if (IG) {   // g_pos = W_in^T dY0 + W5[:, :E_p]^T dY5 (nerf.py:102, :108); dY5 back from its plane
             auto A0 = [&](int sb, int kb) -> const f32x16 & { return act[sb][kb]; };
-            auto A2 = [&](int sb, int kb) -> const f32x16 & { return act[sb][2 + kb]; };
+            auto A2 = [&](int sb, int kb) -> const f32x16 & { return act[sb][(2 + kb) % NFB]; };
             f32x16 gp[2][PB];
-            auto reload = [&]() {
+            auto reload = [&](f32x16 (*dst)[NFB]) {
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                    for (int fb = 0; fb < 4; ++fb)
-                        act[sb][fb] = load_block(gplane(D.g_dy(5)) + (row0 + 32 * sb) * 128, fb, i, h);
+                    for (int fb = 0; fb < NFB; ++fb)
+                        dst[sb][fb] = load_block(gplane(D.g_dy(5)) + (row0 + 32 * sb) * FP, fb, i, h);
             };
             const char *w = lds + pipe.acquire();
-            if constexpr (PB <= 2) {   // pass of 2 blocks: four k-blocks per chunk
+            if constexpr (NFB == 2) {
+                reload(mk);        // (the mask registers are free by now)
+                auto Y5 = [&](int sb, int kb) -> const f32x16 & { return mk[sb][kb]; };
+                if constexpr (PB <= 2) {   // pass of 2 blocks: one chunk = dY0's two k-blocks, then dY5's
+                    auto B = [&](int sb, int kb) -> const f32x16 & { return kb < 2 ? act[sb][kb < 2 ? kb : 0] : mk[sb][kb >= 2 ? kb - 2 : 0]; };
+                    mma_slots2<PB, 4, 2, 0, 16, true>(gp[0], gp[1], B, w, offq, &pipe);
+                } else {                   // pass of 4 blocks: two k-blocks per chunk
+                    mma_slots2<PB, 2, 4, 0, 16, true>(gp[0], gp[1], A0, w, offq, &pipe);
+                    mma_slots2<PB, 2, 4>(gp[0], gp[1], Y5, w + CHUNK_BYTES, offq);
+                }
+                pipe.issue_done();
+            } else if constexpr (PB <= 2) {   // pass of 2 blocks: four k-blocks per chunk
                 mma_slots2<PB, 4, 2, 0, 16, true>(gp[0], gp[1], A0, w, offq, &pipe);
-                reload();
+                reload(act);
                 mma_slots2<PB, 4, 2>(gp[0], gp[1], A0, w + CHUNK_BYTES, offq);
                 pipe.issue_done();
             } else {         // pass of 4 blocks: two k-blocks per chunk, two pairs
                 mma_slots2<PB, 2, 4, 0, 16, true>(gp[0], gp[1], A0, w, offq, &pipe);
                 mma_slots2<PB, 2, 4>(gp[0], gp[1], A2, w + CHUNK_BYTES, offq);
                 pipe.issue_done();
-                reload();
+                reload(act);
                 w = lds + pipe.acquire();
                 mma_slots2<PB, 2, 4, 0, 16>(gp[0], gp[1], A0, w, offq, &pipe);
                 mma_slots2<PB, 2, 4>(gp[0], gp[1], A2, w + CHUNK_BYTES, offq);
@@ -961,9 +999,9 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSB, int PB>
+template <int NSB, int NFB, int PB>
 int launch_reg_fwd(bool record, const WideArgs &a, hipStream_t s) {
-    auto kern = record ? reg_forward_kernel<NSB, PB, true> : reg_forward_kernel<NSB, PB, false>;
+    auto kern = record ? reg_forward_kernel<NSB, NFB, PB, true> : reg_forward_kernel<NSB, NFB, PB, false>;
     static nerf::DeviceMask configured[2] = {{0}, {0}};
     if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), REG_LDS, configured[record],
                                           "nerf_mlp_layered: LDS attribute (register-resident forward)"))
@@ -975,14 +1013,16 @@ int launch_reg_fwd(bool record, const WideArgs &a, hipStream_t s) {
 }
 int launch_reg_forward(bool record, const WideArgs &a, hipStream_t s) {
     const int pb = a.D.Pp / 32;
+    if (a.D.Fp == 64)
+        return pb == 1 ? launch_reg_fwd<2, 2, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<2, 2, 2>(record, a, s) : launch_reg_fwd<2, 2, 3>(record, a, s);
     if (a.D.Fp == 128)
-        return pb == 1 ? launch_reg_fwd<2, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<2, 2>(record, a, s) : launch_reg_fwd<2, 3>(record, a, s);
-    return pb == 1 ? launch_reg_fwd<1, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<1, 2>(record, a, s) : launch_reg_fwd<1, 3>(record, a, s);
+        return pb == 1 ? launch_reg_fwd<2, 4, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<2, 4, 2>(record, a, s) : launch_reg_fwd<2, 4, 3>(record, a, s);
+    return pb == 1 ? launch_reg_fwd<1, 8, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<1, 8, 2>(record, a, s) : launch_reg_fwd<1, 8, 3>(record, a, s);
 }
 
-template <int PB>
+template <int NFB, int PB>
 int launch_narrow_dx_pb(bool ig, const WideArgs &a, hipStream_t s) {
-    auto kern = ig ? narrow_dx_kernel<PB, true> : narrow_dx_kernel<PB, false>;
+    auto kern = ig ? narrow_dx_kernel<NFB, PB, true> : narrow_dx_kernel<NFB, PB, false>;
     static nerf::DeviceMask configured[2] = {{0}, {0}};
     if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), REG_LDS, configured[ig],
                                           "nerf_mlp_layered: LDS attribute (narrow reverse chain)"))
@@ -994,7 +1034,9 @@ int launch_narrow_dx_pb(bool ig, const WideArgs &a, hipStream_t s) {
 }
 int launch_narrow_dx(bool ig, const WideArgs &a, hipStream_t s) {
     const int pb = a.D.Pp / 32;
-    return pb == 1 ? launch_narrow_dx_pb<1>(ig, a, s) : pb == 2 ? launch_narrow_dx_pb<2>(ig, a, s) : launch_narrow_dx_pb<3>(ig, a, s);
+    if (a.D.Fp == 64)
+        return pb == 1 ? launch_narrow_dx_pb<2, 1>(ig, a, s) : pb == 2 ? launch_narrow_dx_pb<2, 2>(ig, a, s) : launch_narrow_dx_pb<2, 3>(ig, a, s);
+    return pb == 1 ? launch_narrow_dx_pb<4, 1>(ig, a, s) : pb == 2 ? launch_narrow_dx_pb<4, 2>(ig, a, s) : launch_narrow_dx_pb<4, 3>(ig, a, s);
 }
 
 // thin reductions of the reverse pass (vector ALU, HBM-bound: one more read of the h7 and h9 planes):
@@ -1003,7 +1045,7 @@ int launch_narrow_dx(bool ig, const WideArgs &a, hipStream_t s) {
 // One wavefront per (32-feature block, slice of the sample axis): a 32-sample tile of the block is 4 KiB = four
 // coalesced 16-byte loads per lane; lane (i, h) keeps the partial sums of sample i of every tile in double, the 32
 // lanes of a half are added up once at the end.  Slices are summed in a fixed order by the second kernel: no atomics.
-constexpr int THIN_SLICES = 256;
+constexpr int THIN_SLICES = 1024;   // (256 single-wavefront slices per block left the kernel latency-bound at 2.4 TB/s)
 __global__ __launch_bounds__(64) void layered_thin_kernel(const Dims D, const float *__restrict__ rec,
                                                           const float *__restrict__ grad, int64_t MP, int slices,
                                                           double *__restrict__ partial) {
@@ -1021,22 +1063,38 @@ __global__ __launch_bounds__(64) void layered_thin_kernel(const Dims D, const fl
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0;
-    for (int64_t t = t0; t < t1; ++t) {
-        const int64_t m = t * 32 + i;
-        const f32x16 x = load_block(plane + t * 32 * width, fb, i, h);
-        if (is_h7) {
-            const double g = (double)ds[m];
-            if (h == 0) ssum[0] += g;
+    // four tiles per trip: their 16 loads are in flight together (one tile at a time, each wavefront sat through a
+    // loaded HBM round trip per 4 KiB: 2.4 TB/s with 12 wavefronts per CU)
+    for (int64_t t = t0; t < t1; t += 4) {
+        f32x16 x[4];
+        float g1[4];
+        f32x4 g4[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] += g * (double)x[r];
-        } else {
-            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gy + 4 * m);
-            if (h == 0) { ssum[1] += (double)g4.x; ssum[2] += (double)g4.y; ssum[3] += (double)g4.z; }
+        for (int j = 0; j < 4; ++j) {
+            const int64_t tj = t + j < t1 ? t + j : t1 - 1;       // past the end: a re-read with zero weights
+            const int64_t m = tj * 32 + i;
+            x[j] = load_block(plane + tj * 32 * width, fb, i, h);
+            if (is_h7) g1[j] = t + j < t1 ? ds[m] : 0.0f;
+            else {
+                g4[j] = *reinterpret_cast<const f32x4 *>(gy + 4 * m);
+                if (t + j >= t1) g4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[0][r] += (double)g4.x * (double)x[r];
-                acc[1][r] += (double)g4.y * (double)x[r];
-                acc[2][r] += (double)g4.z * (double)x[r];
+        for (int j = 0; j < 4; ++j) {
+            if (is_h7) {
+                const double g = (double)g1[j];
+                if (h == 0) ssum[0] += g;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] += g * (double)x[j][r];
+            } else {
+                if (h == 0) { ssum[1] += (double)g4[j].x; ssum[2] += (double)g4[j].y; ssum[3] += (double)g4[j].z; }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[0][r] += (double)g4[j].x * (double)x[j][r];
+                    acc[1][r] += (double)g4[j].y * (double)x[j][r];
+                    acc[2][r] += (double)g4[j].z * (double)x[j][r];
+                }
             }
         }
     }
@@ -1164,8 +1222,14 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
     NERF_REQUIRE(M < (int64_t)1 << 31, "nerf_mlp_layered_forward: more than 2^31 samples per call");
     const Dims D = make_dims(d);
     hipStream_t s = nerf::as_stream(stream);
-    const int64_t chunk = record_rows < M ? record_rows : M;
+    int64_t chunk = record_rows < M ? record_rows : M;
     const Sizes z = sizes(D, chunk, false, 0);
+    // an inference call on a network that fits the register file touches only the two input planes of its scratch:
+    // the same bytes hold recw / (Pp + Dp) times the rows (fewer, longer launches: 12+ tiles per CU instead of one)
+    if (reg_ok(D) && record_rows < M) {
+        const int64_t fit = lrows(record_rows) * D.recw() / (D.Pp + D.Dp) / 256 * 256;
+        chunk = fit < M ? fit : M;
+    }
     char *base = static_cast<char *>(record);
     float *consts = reinterpret_cast<float *>(base);
     float *fstream = reinterpret_cast<float *>(base + z.consts);
@@ -1173,14 +1237,14 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
     // pack (once per call: the parameters may have changed; 2 x the parameter bytes of HBM traffic)
     hipLaunchKernelGGL(layered_pack_consts, dim3(grid_for(D.c_floats())), dim3(256), 0, s, D, params, consts);
     PackArgs pa; pa.D = D; pa.P = params; pa.dx = 0; pa.inputs = 0; pa.n_pairs = stream_pairs(D, 0, 0);
-    hipLaunchKernelGGL(layered_pack_stream, dim3((unsigned)(pa.n_pairs < 1024 ? pa.n_pairs : 1024)), dim3(256), 0, s, pa, fstream);
+    hipLaunchKernelGGL(layered_pack_stream, dim3((unsigned)(pa.n_pairs < 256 ? 16 * pa.n_pairs : 4096)), dim3(256), 0, s, pa, fstream);
     if (int rc = nerf::check_launch("nerf_mlp_layered_forward: pack")) return rc;
     for (int64_t r0 = 0; r0 < M; r0 += chunk) {
         const int64_t rows = M - r0 < chunk ? M - r0 : chunk;
         const int64_t MP = lrows(rows);
-        hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * D.Pp)), dim3(256), 0, s, pos + r0 * D.E_p, rows, MP,
+        hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * 8)), dim3(256), 0, s, pos + r0 * D.E_p, rows, MP,
                            D.E_p, D.Pp, planes + (int64_t)D.r_pe() * MP);
-        hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * D.Dp)), dim3(256), 0, s, view_dir + r0 * D.E_d, rows, MP,
+        hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * 8)), dim3(256), 0, s, view_dir + r0 * D.E_d, rows, MP,
                            D.E_d, D.Dp, planes + (int64_t)D.r_de() * MP);
         if (int rc = nerf::check_launch("nerf_mlp_layered_forward: input planes")) return rc;
         WideArgs a = {};
@@ -1228,14 +1292,14 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
     char *dw_scratch = wbase + zw.dx_stream + zw.planes + thin_bytes;
 
     PackArgs pa; pa.D = D; pa.P = params; pa.dx = 1; pa.inputs = inputs; pa.n_pairs = stream_pairs(D, 1, inputs);
-    hipLaunchKernelGGL(layered_pack_stream, dim3((unsigned)(pa.n_pairs < 1024 ? pa.n_pairs : 1024)), dim3(256), 0, s, pa, dstream);
+    hipLaunchKernelGGL(layered_pack_stream, dim3((unsigned)(pa.n_pairs < 256 ? 16 * pa.n_pairs : 4096)), dim3(256), 0, s, pa, dstream);
     if (int rc = nerf::check_launch("nerf_mlp_layered_backward: pack")) return rc;
     WideArgs a = {};
     a.D = D; a.stream = reinterpret_cast<const char *>(dstream); a.consts = consts;
     a.rec = rec; a.grad = grad; a.M = M; a.MP = MP;
     a.n_passes = dx_num_passes(D, inputs); a.n_pairs = pa.n_pairs; a.inputs = inputs;
     a.sigma_in = sigma; a.rgb_in = rgb; a.g_sigma = g_sigma; a.g_rgb = g_rgb;
-    if (int rc = (reg_ok(D) && D.Fp == 128) ? launch_narrow_dx(inputs != 0, a, s) : launch_program(true, a, s)) return rc;
+    if (int rc = (reg_ok(D) && D.Fp <= 128) ? launch_narrow_dx(inputs != 0, a, s) : launch_program(true, a, s)) return rc;
     if (g_pos) hipLaunchKernelGGL(plane_to_rows_kernel, dim3(grid_for(M * D.E_p)), dim3(256), 0, s,
                                   grad + (int64_t)D.g_gp() * MP, M, D.E_p, D.Pp, g_pos);
     if (g_view_dir) hipLaunchKernelGGL(plane_to_rows_kernel, dim3(grid_for(M * D.E_d)), dim3(256), 0, s,
@@ -1243,7 +1307,7 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
     // thin rows
     {
         const int cols = D.Fp + 3 * D.Hp + 4;
-        int slices = (int)(MP / 32 / 16);          // >= 16 tiles per slice
+        int slices = (int)(MP / 32 / 8);           // >= 8 tiles per slice
         if (slices > THIN_SLICES) slices = THIN_SLICES;
         if (slices < 1) slices = 1;
         hipLaunchKernelGGL(layered_thin_kernel, dim3((D.Fp + D.Hp) / 32, slices), dim3(64), 0, s, D, rec, grad, MP, slices, thin);
