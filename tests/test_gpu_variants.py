@@ -214,6 +214,24 @@ def test_layered_family_any_widths_vs_oracle(oracle, dims, M):
         np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * np.abs(b).max())
 
 
+@pytest.mark.parametrize("dims", [(63, 27, 64), (63, 27, 128), (75, 27, 256), (63, 27, 512), (75, 39, 64)])
+def test_layered_inference_walks_the_batch_in_chunks(monkeypatch, dims):
+    """An inference call (nothing recorded) walks the batch through a scratch of LAYERED_INFERENCE_ROWS rows -- networks
+    whose activations stay in registers take longer chunks out of the same bytes (only the two input planes are
+    touched).  Whatever the chunking, every sample's outputs are the bits the one-launch recorded forward computes;
+    ragged last chunk included."""
+    M = 5000
+    rng = np.random.RandomState(7)
+    pe, de = dev(rng.uniform(-1, 1, (M, dims[0])).astype(np.float32)), dev(rng.uniform(-1, 1, (M, dims[1])).astype(np.float32))
+    fp = dev(synth.nerf_flat_params(seed=4, pos_dim=dims[0], view_dir_dim=dims[1], feat_dim=dims[2], sigma_bias=0.3, sigma_gain=6.0))
+    spec = ops.Net.dims_only(*dims)
+    sigma, rgb, _ = ops.mlp_layered_forward(fp, pe, de, spec, record=True)
+    for rows in (256, 300, 1024):
+        monkeypatch.setattr(ops, "LAYERED_INFERENCE_ROWS", rows)
+        s, c = ops.mlp_layered_forward(fp, pe, de, spec)
+        assert torch.equal(s, sigma) and torch.equal(c, rgb), (dims, rows)
+
+
 def test_layered_gradients_are_deterministic():
     """No atomics: the sliced sample-axis reductions add up in a fixed order."""
     dims = (63, 27, 128)
