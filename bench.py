@@ -470,7 +470,9 @@ def net_variants_leg(device):
 
     out = {"samples": M, "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS}
     gs, gc = torch.randn(M, device=device), torch.randn(M, 3, device=device)
-    for e_p, e_d, F in ((63, 27, 128), (63, 27, 512)):
+    # register-resident kernels: feat 64 (2 x 2 blocks per wavefront), 128 (2 x 4), 256 with three position blocks
+    # (coord_encode_level 12: 1 x 8, general reverse chain); plane-parked general kernel: feat 512
+    for e_p, e_d, F in ((63, 27, 64), (63, 27, 128), (75, 27, 256), (63, 27, 512)):
         H2 = F // 2
         mac = e_p * F + 4 * F * F + (F + e_p) * F + 2 * F * F + F * (F + 1) + (F + e_d) * H2 + 3 * H2
         net = ops.Net.dims_only(e_p, e_d, F)
