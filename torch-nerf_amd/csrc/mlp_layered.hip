@@ -41,6 +41,15 @@ int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int
 int64_t dw_items_scratch_bytes(int n_items);
 }  // namespace nerf
 
+#ifdef X_LAYERED_TIMELINE   // scripts/timeline_layered.py: where workgroup 0 / wavefront 0 of the general kernel spends its cycles
+__device__ unsigned long long g_lt[8];   // drain, operand issue + init, acquire waits, MFMA loops, epilogue, between passes, passes
+#define LT_NOW() __builtin_readcyclecounter()
+#define LT_ADD(k, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lt[k] += (v); } while (0)
+#else
+#define LT_NOW() 0ull
+#define LT_ADD(k, v) do { (void)(v); } while (0)
+#endif
+
 namespace {
 
 using namespace mlp;
@@ -390,28 +399,47 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
     const int pairs = P.pairs(), chunks = P.chunks();
 
     f32x16 bA[2 * KPC], bB[2 * KPC];
+    const unsigned long long lt0 = LT_NOW();
     // the sources were stored by this very wavefront one pass ago (asm-issued stores): drain them, then read back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long lt1 = LT_NOW();
+    unsigned long long lt_acq = 0;
     load_b_pair<KPC>(bA, P, 0, src0, src1, c);
 
     f32x16 acc[NFB];
-    {   // initial accumulators: bias window / density row x dsigma' / zero (all rows of the constant block are padded)
-        const float *row = a.consts + P.init_off;
+    // initial accumulators: bias window / density row x dsigma' / zero.  ONE wave-uniform branch: a condition inside the
+    // (fb, q) loops became a scalar branch per element group (the timeline of scripts/timeline_layered.py: 2 k cycles here
+    // and 13 k in the epilogue of a 148 k-cycle pass, all of it s_cbranch).  Blocks the pass does not have start from the
+    // first block's values: their weight slots are zero and nothing stores them.
+    if (P.init == INIT_ZERO) {
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
+            for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
+    } else {
+        const float *row = a.consts + P.init_off;
+        const float s = (DX && P.init == INIT_DENSITY) ? dsig : 1.0f;
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+            const float *rb = row + 32 * (fb < P.blocks ? fb : 0);     // scalar select
+#pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (P.init != INIT_ZERO && fb < P.blocks) v = *reinterpret_cast<const f32x4 *>(row + 32 * fb + 8 * q + 4 * c.h);
-                const float s = (DX && P.init == INIT_DENSITY) ? dsig : 1.0f;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(rb + 8 * q + 4 * c.h);
                 acc[fb][4 * q + 0] = v.x * s; acc[fb][4 * q + 1] = v.y * s;
                 acc[fb][4 * q + 2] = v.z * s; acc[fb][4 * q + 3] = v.w * s;
             }
+        }
     }
     if (!DX && P.side == SIDE_DENSITY) sig = 0.0f;
 
     f32x16 mk[NFB];          // DX: the forward activations whose sign masks this pass's result
     const bool masked = DX && P.mask_off >= 0;
+    if (DX && !masked) {     // an unmasked stage keeps everything: the epilogue below has no branch
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mk[fb][r] = 1.0f;
+    }
     const char *mtile = masked ? tile_of(a.rec, P.mask_off, P.dst_w, a.MP, c.row0) + (size_t)P.dst_fb0 * 4096 : nullptr;
 
     // the density row of fc_8 rides on the B operands streaming by (nerf.py:113-115): sigma' = W8[0, :] . h7 + b
@@ -431,20 +459,23 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
         }
     };
 
+    const unsigned long long lt2 = LT_NOW();
     for (int pr = 0; pr < pairs; pr += 2) {
         {   // even pair: operands bA, next pair's into bB
+            const unsigned long long la = LT_NOW();
             const char *w = c.lds + pipe.acquire();
+            lt_acq += LT_NOW() - la;
             if (pr + 1 < pairs) load_b_pair<KPC>(bB, P, (pr + 1) * 2 * KPC, src0, src1, c);
             if (masked && pr + 1 >= pairs) {
 #pragma unroll
-                for (int fb = 0; fb < NFB; ++fb)
-                    if (fb < P.blocks) {
+                for (int fb = 0; fb < NFB; ++fb) {
+                    const char *mb = mtile + (fb < P.blocks ? fb : 0) * 4096;    // (blocks the pass does not have: any finite plane)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x4 v = load16_s(mtile + fb * 4096, c.voff[q], q * 1024);
-                            mk[fb][4 * q + 0] = v.x; mk[fb][4 * q + 1] = v.y; mk[fb][4 * q + 2] = v.z; mk[fb][4 * q + 3] = v.w;
-                        }
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = load16_s(mb, c.voff[q], q * 1024);
+                        mk[fb][4 * q + 0] = v.x; mk[fb][4 * q + 1] = v.y; mk[fb][4 * q + 2] = v.z; mk[fb][4 * q + 3] = v.w;
                     }
+                }
             }
             if (!DX && P.side == SIDE_DENSITY) density(bA, pr * 2 * KPC);
             mma_slots<NFB, KPC, 0, 16>(acc, bA, w, c.offq, &pipe);
@@ -452,18 +483,20 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
             pipe.issue_done();
         }
         if (pr + 1 < pairs) {   // odd pair: operands bB, next pair's into bA
+            const unsigned long long la = LT_NOW();
             const char *w = c.lds + pipe.acquire();
+            lt_acq += LT_NOW() - la;
             if (pr + 2 < pairs) load_b_pair<KPC>(bA, P, (pr + 2) * 2 * KPC, src0, src1, c);
             if (masked && pr + 2 >= pairs) {
 #pragma unroll
-                for (int fb = 0; fb < NFB; ++fb)
-                    if (fb < P.blocks) {
+                for (int fb = 0; fb < NFB; ++fb) {
+                    const char *mb = mtile + (fb < P.blocks ? fb : 0) * 4096;    // (blocks the pass does not have: any finite plane)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x4 v = load16_s(mtile + fb * 4096, c.voff[q], q * 1024);
-                            mk[fb][4 * q + 0] = v.x; mk[fb][4 * q + 1] = v.y; mk[fb][4 * q + 2] = v.z; mk[fb][4 * q + 3] = v.w;
-                        }
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = load16_s(mb, c.voff[q], q * 1024);
+                        mk[fb][4 * q + 0] = v.x; mk[fb][4 * q + 1] = v.y; mk[fb][4 * q + 2] = v.z; mk[fb][4 * q + 3] = v.w;
                     }
+                }
             }
             if (!DX && P.side == SIDE_DENSITY) density(bB, (pr + 1) * 2 * KPC);
             mma_slots<NFB, KPC, 0, 16>(acc, bB, w, c.offq, &pipe);
@@ -473,13 +506,17 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
     }
 
     // ---- epilogue
+    const unsigned long long lt3 = LT_NOW();
+    LT_ADD(0, lt1 - lt0); LT_ADD(1, lt2 - lt1); LT_ADD(2, lt_acq); LT_ADD(3, lt3 - lt2 - lt_acq); LT_ADD(6, 1ull);
+    // branch-free: ReLU as max(v, floor) with floor = 0 | -inf in a scalar register; the reverse chain always selects
+    const float floor = P.relu ? 0.0f : -__builtin_inff();
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[fb][r];
-            if (P.relu) v = relu1(v);
-            if (masked) v = mk[fb][r] > 0.0f ? v : 0.0f;
+            if (!DX) asm("v_max_f32 %0, %1, %2" : "=v"(v) : "s"(floor), "v"(acc[fb][r]));
+            else v = mk[fb][r] > 0.0f ? v : 0.0f;
             acc[fb][r] = v;
         }
     float *dbuf = P.dst_buf ? a.grad : a.rec;
@@ -515,6 +552,7 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
             if (c.valid && c.h == 0) { a.rgb[3 * c.m] = y0; a.rgb[3 * c.m + 1] = y1; a.rgb[3 * c.m + 2] = y2; }
         }
     }
+    LT_ADD(4, LT_NOW() - lt3);
 }
 
 template <bool DX>
@@ -541,6 +579,13 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
     pipe.issue();
 
     const int64_t ntiles = a.MP / TILE_SAMPLES;
+#ifdef X_STAGGER_TICKS   // experiment: workgroups start spread over X_STAGGER_TICKS x 10 ns so that their epilogues do not coincide
+    {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)blockIdx.x * X_STAGGER_TICKS / gridDim.x;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         c.row0 = tile * TILE_SAMPLES + wave * 32;
         c.m = c.row0 + c.i;
@@ -584,7 +629,10 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
             }
         }
         for (int p = 0; p < a.n_passes; ++p) {
+            const unsigned long long lp = LT_NOW();
             const Pass P = DX ? dx_pass(a.D, a.inputs, p) : fwd_pass(a.D, p);
+            // (the stamp must follow the program: a scalar of it orders the reads)
+            LT_ADD(5, LT_NOW() - lp + (unsigned long long)(P.nfb & 0));
             if (P.nfb == 8) run_pass<8, DX>(P, a, c, pipe, pr0, pr1, pr2, sig, dsig);
             else if (P.nfb == 4) run_pass<4, DX>(P, a, c, pipe, pr0, pr1, pr2, sig, dsig);
             else run_pass<2, DX>(P, a, c, pipe, pr0, pr1, pr2, sig, dsig);
@@ -1158,6 +1206,15 @@ Sizes sizes(const Dims &D, int64_t rows, bool backward, int inputs) {
     s.planes = align256b(4 * lrows(rows) * (int64_t)(backward ? D.gradw() : D.recw()));
     return s;
 }
+
+#ifdef X_LAYERED_TIMELINE
+extern "C" __attribute__((visibility("default"))) int nerf_debug_layered_timeline(unsigned long long *out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lt), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lt), z, sizeof(z)); }
+    return 8;
+}
+#endif
 
 int launch_program(bool dx, const WideArgs &a, hipStream_t s) {
     auto kern = dx ? layered_kernel<true> : layered_kernel<false>;
