@@ -457,16 +457,21 @@ def net_variants_leg(device):
     from torch_nerf.amd import ops, synth
     M = RAYS * (N_COARSE + N_FINE)          # 786 432: the sample count of the headline's fine pass
 
-    def t(fn, n=3):
+    def t(fn, window_ms=120.0):
+        """mean duration of fn over ~window_ms of back-to-back calls (a 0.8 ms call timed three times measures the
+        clock ramp of an idle chip, not the kernels: 10 % low)"""
+        def run(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
         fn()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
+        once = run(2)
+        return run(max(3, min(200, int(window_ms / max(once, 1e-3)))))
 
     out = {"samples": M, "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS}
     gs, gc = torch.randn(M, device=device), torch.randn(M, 3, device=device)

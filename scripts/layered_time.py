@@ -5,13 +5,15 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "torch-nerf_amd")]
 import numpy as np, torch
 from torch_nerf.amd import ops, synth
 torch.cuda.set_device(0)
-def t(fn, n=5):
+def t(fn, window_ms=120.0):   # mean over ~window_ms of back-to-back calls (as bench.py's net_variants leg)
+    def run(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
     fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
+    return run(max(3, min(200, int(window_ms / max(run(2), 1e-3)))))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 NETS = ((63, 27, 256), (75, 27, 256), (63, 27, 128), (63, 27, 64), (75, 39, 64), (63, 27, 512))
 if len(sys.argv) > 2:   # e.g. "128,512": feat_dims to run (profiling passes)
