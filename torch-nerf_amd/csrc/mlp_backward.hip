@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
                     }
                 }
         }
-        save_plane<4, true>(dy + dy9_plane(MP), 128, m, h, act);
+        // (plane stores ride between the MFMA groups of the pairs that multiply the stored blocks: PlaneStore, mlp_device.h)
+        PlaneStore st9;
+        st9.open(dy + dy9_plane(MP), 128, m, h, act);
         mk = masks[(int64_t)7 * MP * 2 + 2 * m + h];   // for the seam of l = 7
 
         if (IG) {   // g_view_dir = W9[:, 256:]^T dY9 (nerf.py:116: the direction is the tail of fc_9's input)
@@ -164,9 +166,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
             w = lds + pipe.acquire();
         }
         // ---- d y8[1:257] = W9[:, 0:256]^T dY9   (fc_9 input is cat([x[:,1:], dir]): nerf.py:116)
-        mma_pair<8, true>(acc, act[0], act[1], w, offq, pipe);   // accumulators start from C = 0
+        mma_pair<8, true, 8>(acc, act[0], act[1], w, offq, pipe, &st9, 0);   // accumulators start from C = 0
         w = lds + pipe.acquire();
-        mma_pair<8>(acc, act[2], act[3], w, offq, pipe);
+        mma_pair<8, false, 8>(acc, act[2], act[3], w, offq, pipe, &st9, 8);
 
         // ---- l = 8 .. 1:  dY(l-1) = (W_l^T dY(l)) . [h(l-1) > 0]
         TS();
@@ -186,7 +188,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
                     for (int r = 0; r < 16; ++r) act[fb][r] = masked(mk, fb, r, acc[fb][r]);
                 mk = masks[(int64_t)(l - 1) * MP * 2 + 2 * m + h];   // h(l-1): next seam (l = 1: the dY0 epilogue)
             }
-            save_plane<8, true>(dy + dy_plane(MP, l), 256, m, h, act);
+            PlaneStore st;
+            st.open(dy + dy_plane(MP, l), 256, m, h, act);
             if (l == 8) {  // the density row of fc_8 contributes w8[0, k] * d y8[0]
 #pragma unroll
                 for (int fb = 0; fb < 8; ++fb)
@@ -198,13 +201,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
                     }
             }
             TS();
-            if (l == 8) mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
-            else mma_pair<8, true>(acc, act[0], act[1], w, offq, pipe);   // accumulators start from C = 0
+            if (l == 8) mma_pair<8, false, 8>(acc, act[0], act[1], w, offq, pipe, &st, 0);
+            else mma_pair<8, true, 8>(acc, act[0], act[1], w, offq, pipe, &st, 0);   // accumulators start from C = 0
             TS();
 #pragma unroll
             for (int pr = 1; pr < 4; ++pr) {
                 w = lds + pipe.acquire();
-                mma_pair<8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
+                mma_pair<8, false, 8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe, &st, 8 * pr);
             }
         }
         TS();

@@ -207,10 +207,42 @@ __device__ __forceinline__ void lds_fragments_ready() {
     __builtin_amdgcn_sched_barrier(0);  // ... and the consumers of the fragment stay below it
 }
 
-template <int NFB, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false>
+// A plane store spread over the MFMA stream (record forward, dX chain): the 4 NFB one-KiB stores of save_plane(),
+// issued one at a time between MFMA groups instead of back to back at the layer seam.  A wavefront gets a 1-KiB store
+// out every ~190 cycles (four wavefronts share the CU's ~16 B / clock store path: scripts/timeline_layered.py), and at
+// the seam nothing hides that: 32 stores = 6 k cycles of a 65 k-cycle layer.  The blocks stored must stay untouched
+// until the last store has been issued (they are the B operands of the layer being multiplied: they do).
+struct PlaneStore {
+    uint64_t tile;         // address of this wavefront's 32-sample tile of the plane (wave-uniform: SGPR pair)
+    unsigned unit16;       // (2 i + h) << 4
+    const f32x16 *blk;
+    __device__ __forceinline__ void open(float *plane, int width, int64_t m, int h, const f32x16 *blocks) {
+        const int i = (int)(m & 31);
+        const uint64_t a = reinterpret_cast<uint64_t>(plane + (m - i) * width);
+        tile = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+        unit16 = (unsigned)(2 * i + h) << 4;
+        blk = blocks;
+    }
+    // store s = 4 fb + q (the order save_plane() walks); `s` is a constant after unrolling
+    __device__ __forceinline__ void issue(int s) const {
+        const int fb = s >> 2, q = s & 3;
+        const f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
+        // (s_nop 4 in front: the scalar base may come straight out of a v_readfirstlane / SALU add -- see save_plane();
+        // s_nop 1 behind: wide-store data hazard, inside the statement)
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
+                     : : "v"(unit16 ^ (32u * q)), "v"(v), "s"(tile + (uint64_t)fb * 4096u), "n"(q * 1024) : "memory");
+    }
+};
+
+// N_STORES > 0: stores FIRST_STORE .. FIRST_STORE + N_STORES - 1 of `st` are issued between the groups of this chunk too.
+template <int NFB, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false, int N_STORES = 0>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, const char *chunk,
-                                          const int (&offq)[4], const Pipe *pipe = nullptr) {
+                                          const int (&offq)[4], const Pipe *pipe = nullptr, const PlaneStore *st = nullptr,
+                                          int first_store = 0) {
     constexpr int GROUPS = 4 * NFB, EVERY = GROUPS / (N_PIECES > 0 ? N_PIECES : GROUPS);
+    constexpr int SEVERY = GROUPS / (N_STORES > 0 ? N_STORES : GROUPS);
+    static_assert(N_STORES == 0 || GROUPS % N_STORES == 0, "stores spread evenly over the groups");
     // A fragments are fetched one (q, fb) group ahead of the MFMAs that consume them, into two
     // alternating buffers: a ds_read_b128 issued behind a group's last MFMA returns ~80 cycles
     // later than the matrix pipe frees up, which with a single buffer costs ~14 idle cycles per group.
@@ -235,6 +267,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, con
         acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * q + 1], acc[fb], 0, 0, 0);
         if (N_PIECES > 0 && g % EVERY == 0) pipe->issue_piece(FIRST_PIECE + g / EVERY);
         acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * q + 2], acc[fb], 0, 0, 0);
+        if (N_STORES > 0 && g % SEVERY == SEVERY - 1) st->issue(first_store + g / SEVERY);
         acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * q + 3], acc[fb], 0, 0, 0);
     }
 }
@@ -324,10 +357,13 @@ __device__ __forceinline__ void mma_slots2(f32x16 *acc0, f32x16 *acc1, BSel bsel
 // One pipeline step: both chunks of the acquired pair.  The next pair's 16 DMA pieces are all
 // issued during the FIRST chunk, so the youngest of them still has a whole chunk of MFMAs
 // (8 k cycles) to land before the next acquire waits for it.
-template <int NFB, bool FRESH = false>
+// N_STORES > 0: that many stores of `st`, from `first_store` on, ride in the first chunk as well (they too have the
+// second chunk to complete before the next acquire's vmcnt(0)).
+template <int NFB, bool FRESH = false, int N_STORES = 0>
 __device__ __forceinline__ void mma_pair(f32x16 (&acc)[8], const f32x16 &b0, const f32x16 &b1, const char *w,
-                                         const int (&offq)[4], Pipe &pipe) {
-    mma_chunk<NFB, 0, 16, FRESH>(acc, b0, w, offq, &pipe);
+                                         const int (&offq)[4], Pipe &pipe, const PlaneStore *st = nullptr,
+                                         int first_store = 0) {
+    mma_chunk<NFB, 0, 16, FRESH, N_STORES>(acc, b0, w, offq, &pipe, st, first_store);
     mma_chunk<NFB>(acc, b1, w + CHUNK_BYTES, offq);
     pipe.issue_done();
 }

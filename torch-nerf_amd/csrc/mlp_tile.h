@@ -127,8 +127,11 @@ __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[
         for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) act[fb][r] = relu1(acc[fb][r]);  // ReLU of layer l-1
+        // record: h(l-1) leaves in 32 one-KiB stores spread over the first chunks of this layer's four pairs (its blocks
+        // are the B operands of exactly these pairs: untouched until the next seam) -- at the seam they cost ~190 cycles each
+        PlaneStore st;
         if (SAVE) {
-            save_plane<8>(saved + pl_h(MP, l - 1), 256, m, h, act);
+            st.open(saved + pl_h(MP, l - 1), 256, m, h, act);
             save_mask<8>(saved + pl_masks(MP) + (int64_t)(l - 1) * MP * 8, m, h, act);
         }
         if (l == 8) sigma_pre = half_dot<8>(cb + CB_W8ROW0, act, h);  // density row of fc_8
@@ -138,12 +141,12 @@ __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[
             mma_pair<8>(acc, pe[0], pe[1], w, offq, pipe);
             w = lds + pipe.acquire();
         }
-        mma_pair<8>(acc, act[0], act[1], w, offq, pipe);
+        mma_pair<8, false, SAVE ? 8 : 0>(acc, act[0], act[1], w, offq, pipe, &st, 0);
         NERF_TS();
 #pragma unroll
         for (int pr = 1; pr < 4; ++pr) {
             w = lds + pipe.acquire();
-            mma_pair<8>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
+            mma_pair<8, false, SAVE ? 8 : 0>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe, &st, 8 * pr);
         }
     }
 
@@ -155,7 +158,8 @@ __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[
         const char *w = lds + pipe.acquire();
 #pragma unroll
         for (int fb = 0; fb < 8; ++fb) act[fb] = acc[fb];
-        if (SAVE) save_plane<8>(saved + pl_y8(MP), 256, m, h, act);
+        PlaneStore st;
+        if (SAVE) st.open(saved + pl_y8(MP), 256, m, h, act);     // y8: spread over fc_9's four pairs
         if (RAYDIR) {
             load_bias<4>(acc, fc9_init, h);           // this lane's ray: bias + direction part, as the chain below leaves it
         } else {
@@ -164,11 +168,11 @@ __device__ __forceinline__ void forward_tile(const Net &net, const float (&raw)[
             pipe.issue_done();
             w = lds + pipe.acquire();
         }
-        mma_pair<4>(acc, act[0], act[1], w, offq, pipe);
+        mma_pair<4, false, SAVE ? 8 : 0>(acc, act[0], act[1], w, offq, pipe, &st, 0);
 #pragma unroll
         for (int pr = 1; pr < 4; ++pr) {
             w = lds + pipe.acquire();
-            mma_pair<4>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe);
+            mma_pair<4, false, SAVE ? 8 : 0>(acc, act[2 * pr], act[2 * pr + 1], w, offq, pipe, &st, 8 * pr);
         }
     }
     NERF_TS();
