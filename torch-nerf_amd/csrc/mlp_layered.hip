@@ -699,25 +699,17 @@ __device__ __forceinline__ void run_blocks(f32x16 *acc0, f32x16 *acc1, Seq seq, 
     constexpr int CH = (N + KPCX - 1) / KPCX, LAST = N - (CH - 1) * KPCX;   // chunks; k-blocks of the last one
     const char *w = w0;       // (ACQ_FIRST: the first pair is acquired here; a template flag, not `w0 == nullptr`: no run-time
                               // branch may sit around an acquire, and LDS address 0 is a valid pointer)
-    // (a plain unrolled loop: every `c` below is a constant after unrolling and the untaken arms disappear; nested
-    // template lambdas here cost the reverse chain ~100 spilled registers)
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
+    static_for<CH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
         if (c % 2 == 0 && (c > 0 || ACQ_FIRST)) w = lds + pipe.acquire();
         before(c);
         auto b = [&](int sb, int kb) -> const f32x16 & { return seq(sb, c * KPCX + kb); };
         const char *wc = w + (c % 2) * CHUNK_BYTES;
-        if (c == CH - 1) {
-            if (c == 0) mma_slots2<NFBC, LAST, STRIDE, 0, 16, FRESH, NSB>(acc0, acc1, b, wc, offq, &pipe);
-            else if (c % 2 == 0) mma_slots2<NFBC, LAST, STRIDE, 0, 16, false, NSB>(acc0, acc1, b, wc, offq, &pipe);
-            else mma_slots2<NFBC, LAST, STRIDE, 0, 0, false, NSB>(acc0, acc1, b, wc, offq);
-        } else {
-            if (c == 0) mma_slots2<NFBC, KPCX, STRIDE, 0, 16, FRESH, NSB>(acc0, acc1, b, wc, offq, &pipe);
-            else if (c % 2 == 0) mma_slots2<NFBC, KPCX, STRIDE, 0, 16, false, NSB>(acc0, acc1, b, wc, offq, &pipe);
-            else mma_slots2<NFBC, KPCX, STRIDE, 0, 0, false, NSB>(acc0, acc1, b, wc, offq);
-        }
+        constexpr int NKBX = c == CH - 1 ? LAST : KPCX;
+        if constexpr (c % 2 == 0) mma_slots2<NFBC, NKBX, STRIDE, 0, 16, (FRESH && c == 0), NSB>(acc0, acc1, b, wc, offq, &pipe);
+        else mma_slots2<NFBC, NKBX, STRIDE, 0, 0, false, NSB>(acc0, acc1, b, wc, offq);
         if (c % 2 == 1 || c == CH - 1) pipe.issue_done();
-    }
+    });
 }
 
 // (NSB sample blocks, NFB feature blocks) per wavefront: (1, 8) = feat_dim 225..256, (2, 4) = 97..128, (2, 2) = 33..64
@@ -785,6 +777,9 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
                 for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) act[sb][fb][r] = relu1(acc[sb][fb][r]);
+            // (the stores stay at the seam here: spread over the MFMA groups like the fused family's (PlaneStore) they need a
+            // four-register copy each while accumulators, activations and encodings are all live -- 25..250 B of scratch in
+            // every record variant and 3-5 % slower; at the seam the dead accumulators lend the registers)
             if (RECORD) {
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) save_plane<NFB, true>(plane(D.r_h(l - 1)), FP, m[sb], h, act[sb]);
@@ -972,8 +967,9 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
                         mk[sb][fb] = load_block(rplane(D.r_h(l - 1)) + (row0 + 32 * sb) * FP, fb, i, h);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            save_plane<NFB, true>(gplane(D.g_dy(l)), FP, m[0], h, act[0]);
-            save_plane<NFB, true>(gplane(D.g_dy(l)), FP, m[1], h, act[1]);
+            PlaneStore st[2];     // dY(l) leaves between the MFMA groups of the first chunk
+            st[0].open(gplane(D.g_dy(l)), FP, m[0], h, act[0]);
+            st[1].open(gplane(D.g_dy(l)), FP, m[1], h, act[1]);
             auto A0 = [&](int sb, int kb) -> const f32x16 & { return act[sb][kb]; };
             auto A2 = [&](int sb, int kb) -> const f32x16 & { return act[sb][(2 + kb) % NFB]; };
             if (l == 8) {   // + W8[0, :] dsigma' (the density row)
@@ -987,9 +983,9 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[sb][fb][4 * q + j] = wv[j] * dsig[sb];
                         }
-                mma_slots2<NFB, 2, NFB, 0, 16>(acc[0], acc[1], A0, w, offq, &pipe);
+                mma_slots2<NFB, 2, NFB, 0, 16, false, 2, 8 * NFB, 4 * NFB, 8 * NFB>(acc[0], acc[1], A0, w, offq, &pipe, st, 0);
             } else {
-                mma_slots2<NFB, 2, NFB, 0, 16, true>(acc[0], acc[1], A0, w, offq, &pipe);
+                mma_slots2<NFB, 2, NFB, 0, 16, true, 2, 8 * NFB, 4 * NFB, 8 * NFB>(acc[0], acc[1], A0, w, offq, &pipe, st, 0);
             }
             // (NFB = 2: the layer's two k-blocks are the first half of the pair's first chunk)
             if constexpr (NFB == 4) mma_slots2<4, 2, 4>(acc[0], acc[1], A2, w + CHUNK_BYTES, offq);
