@@ -17,21 +17,21 @@ g = torch.empty(lib.nerf_mlp_param_count(None), device="cuda")
 for _ in range(2):
     ws.zero_()
     rc = lib.nerf_mlp_backward(None, packed.data_ptr(), flat.data_ptr(), pts.data_ptr(), dirs.data_ptr(), M, 0, sigma.data_ptr(),
-                               rgb.data_ptr(), saved.data_ptr(), gs.data_ptr(), gc.data_ptr(), g.data_ptr(), ws.data_ptr(),
+                               rgb.data_ptr(), saved.data_ptr(), gs.data_ptr(), gc.data_ptr(), g.data_ptr(), None, None, ws.data_ptr(),
                                torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()
 MP = (M + 127) // 128 * 128
-off = (MP * 2433 + 255) // 256 * 256 + (2 * 256 + 13) * (256 * 256 + 256) - 65536
+off = (MP * 2533 + 255) // 256 * 256 + (2 * 256 + 13) * (256 * 256 + 256) - 65536
 t = ws[off:off + 65536].view(torch.int64).cpu().numpy()
 t = t[t != 0]
-per_tile = 2 + 8 * 4 + 1
+per_tile = 5 + 8 * 4 + 1
 n = len(t) // per_tile
 print("stamps", len(t), "tiles", n)
 t = t[: n * per_tile].reshape(n, per_tile)
 d = np.diff(t, axis=1)[1:-1].mean(0)
 print("tile period", np.diff(t[:, 0]).mean())
-names = ["head: fc_out^T, dY9 store, fc_9^T (2 pairs)"]
+names = ["head: loads issued, gy", "head: acquire (vmcnt(0): the loads, the previous tile's dY0 stores)", "head: dY9 on the vector ALU", "head: fc_9^T (2 pairs)"]
 for l in range(8, 0, -1):
     names += [f"L{l}: tail of previous pairs", "  acquire", "  seam (mask, store dY, zero acc)", "  pair 0", ]
     names[-4] = f"L{l}: pairs 1-3 of previous layer" if l < 8 else "L8: -"

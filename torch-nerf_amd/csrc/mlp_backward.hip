@@ -113,14 +113,19 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
             cbt = cb + zero;
         }
         // fc_out + sigmoid (nerf.py:119): d y10 = g_rgb * rgb * (1 - rgb)
-        float gy[3];
+        // (all eight loads first, from the clamped row: written as `valid ? g_rgb[..] * .. : 0` they became five
+        // load-then-wait sequences under exec masks, 12 k cycles of HBM latency per tile)
+        float gy[3], yv[3], gv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { yv[c] = rgb[3 * mc + c]; gv[c] = g_rgb[3 * mc + c]; }
+        const float sg = sigma[mc], gsg = g_sigma[mc];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float y = rgb[3 * mc + c];
-            gy[c] = valid ? g_rgb[3 * mc + c] * y * (1.0f - y) : 0.0f;
+            const float t = gv[c] * yv[c] * (1.0f - yv[c]);
+            gy[c] = valid ? t : 0.0f;
         }
         // sigma = relu(y8[0]) (nerf.py:115)
-        const float dsig = (valid && sigma[mc] > 0.0f) ? g_sigma[mc] : 0.0f;
+        const float dsig = (valid && sg > 0.0f) ? gsg : 0.0f;
         if (h == 0) {   // the fc_out weight gradient is summed beside the fc_9 GEMM of the dW kernel, from this plane
             const f32x4 g4 = {gy[0], gy[1], gy[2], 0.0f};
             *reinterpret_cast<f32x4 *>(dy + gy_plane(MP) + 4 * m) = g4;
@@ -137,7 +142,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         // ReLU masks are fetched one stage ahead of their use: a 16-byte global load issued inside the seam that
         // needs it costs its whole latency there (no MFMA is in flight to cover it)
         u32x4 mk = masks[(int64_t)8 * MP * 2 + 2 * m + h];
+        TS();
         const char *w = lds + pipe.acquire();
+        TS();
         {
 #pragma unroll
             for (int fb = 0; fb < 4; ++fb)
@@ -158,6 +165,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(const char *__restri
         PlaneStore st9;
         st9.open(dy + dy9_plane(MP), 128, m, h, act);
         mk = masks[(int64_t)7 * MP * 2 + 2 * m + h];   // for the seam of l = 7
+        TS();
 
         if (IG) {   // g_view_dir = W9[:, 256:]^T dY9 (nerf.py:116: the direction is the tail of fc_9's input)
             mma_slots<1, 4, 0, 16, true>(acc, act, w, offq, &pipe);

@@ -595,13 +595,16 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
             // ---- heads (nerf.py:115, :119): d y10 = g_rgb rgb (1 - rgb), dsigma' = g_sigma . [sigma > 0]; then
             // dY9 = (W_out^T d y10) . [h9 > 0] on the vector ALU, block by block
             const int64_t mc = c.valid ? c.m : a.M - 1;
-            float gy[3];
+            float gy[3], yv[3], gv[3];      // (all loads first, from the clamped row: no load-then-wait chains under exec masks)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { yv[ch] = a.rgb_in[3 * mc + ch]; gv[ch] = a.g_rgb[3 * mc + ch]; }
+            const float sg = a.sigma_in[mc], gsg = a.g_sigma[mc];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const float y = a.rgb_in[3 * mc + ch];
-                gy[ch] = c.valid ? a.g_rgb[3 * mc + ch] * y * (1.0f - y) : 0.0f;
+                const float t = gv[ch] * yv[ch] * (1.0f - yv[ch]);
+                gy[ch] = c.valid ? t : 0.0f;
             }
-            dsig = (c.valid && a.sigma_in[mc] > 0.0f) ? a.g_sigma[mc] : 0.0f;
+            dsig = (c.valid && sg > 0.0f) ? gsg : 0.0f;
             if (c.h == 0) {
                 const f32x4 g4 = {gy[0], gy[1], gy[2], 0.0f};
                 *reinterpret_cast<f32x4 *>(a.grad + (int64_t)a.D.g_gy() * a.MP + 4 * c.m) = g4;
@@ -900,13 +903,16 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
         for (int sb = 0; sb < 2; ++sb) {
             const bool valid = m[sb] < a.M;
             const int64_t mc = valid ? m[sb] : a.M - 1;
-            float gy[3];
+            float gy[3], yv[3], gv[3];      // (all loads first, from the clamped row: no load-then-wait chains under exec masks)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { yv[ch] = a.rgb_in[3 * mc + ch]; gv[ch] = a.g_rgb[3 * mc + ch]; }
+            const float sg = a.sigma_in[mc], gsg = a.g_sigma[mc];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const float y = a.rgb_in[3 * mc + ch];
-                gy[ch] = valid ? a.g_rgb[3 * mc + ch] * y * (1.0f - y) : 0.0f;
+                const float t = gv[ch] * yv[ch] * (1.0f - yv[ch]);
+                gy[ch] = valid ? t : 0.0f;
             }
-            dsig[sb] = (valid && a.sigma_in[mc] > 0.0f) ? a.g_sigma[mc] : 0.0f;
+            dsig[sb] = (valid && sg > 0.0f) ? gsg : 0.0f;
             if (h == 0) {
                 const f32x4 g4 = {gy[0], gy[1], gy[2], 0.0f};
                 *reinterpret_cast<f32x4 *>(gplane(D.g_gy()) + 4 * m[sb]) = g4;
