@@ -284,9 +284,12 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[8], const f32x16 &b, con
 // The same for a SLOT-MAJOR chunk (mlp_layout.h, input-gradient pairs of the transposed stream): eight 4-KiB slots, slot
 // kb * NFB + fb = rows 32 fb .. 32 fb + 31 of the (thin) output x the 32 k-values of operand b[kb], NKB * NFB <= 8:
 //   acc[fb] += sum over kb of W_slot(kb, fb) . b[kb]
-template <int NFB, int NKB, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false>
+struct NoHook { __device__ __forceinline__ void operator()(int, int) const {} };
+// `hook(g, GROUPS)` runs once in every MFMA group (the layered kernel's operand loads for the NEXT pair ride there: a
+// wavefront gets a 1-KiB vector-memory instruction out every 60..190 cycles, and in front of the MFMAs that is exposed).
+template <int NFB, int NKB, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false, class Hook = NoHook>
 __device__ __forceinline__ void mma_slots(f32x16 *acc, const f32x16 *b, const char *chunk, const int (&offq)[4],
-                                          const Pipe *pipe = nullptr) {
+                                          const Pipe *pipe = nullptr, Hook hook = Hook()) {
     static_assert(NFB * NKB <= 8, "a chunk holds eight slots");
     constexpr int GROUPS = 4 * NFB * NKB, EVERY = GROUPS / (N_PIECES > 0 ? N_PIECES : GROUPS);
     const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)chunk;
@@ -313,6 +316,7 @@ __device__ __forceinline__ void mma_slots(f32x16 *acc, const f32x16 *b, const ch
         acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[kb][4 * q + 1], acc[fb], 0, 0, 0);
         if (N_PIECES > 0 && g % EVERY == 0 && g / EVERY < N_PIECES) pipe->issue_piece(FIRST_PIECE + g / EVERY);
         acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[kb][4 * q + 2], acc[fb], 0, 0, 0);
+        hook(g, GROUPS);
         acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[kb][4 * q + 3], acc[fb], 0, 0, 0);
     }
 }

@@ -387,6 +387,19 @@ __device__ __forceinline__ void load_b_pair(f32x16 (&b)[2 * KPC], const Pass &P,
     __builtin_amdgcn_sched_barrier(0);   // the loads stay here, a pair ahead of their use
 }
 
+// the same, one 16-byte load at a time: load n = 4 j + q of the pair (j = k-block of the pair, q = 16-byte group) -- issued
+// from inside the MFMA groups of the previous pair (mma_slots' hook)
+template <int KPC>
+__device__ __forceinline__ void load_b_one(f32x16 (&b)[2 * KPC], const Pass &P, int kb_first, const char *src0,
+                                           const char *src1, const Ctx &c, int n) {
+    const int j = n >> 2, q = n & 3, total = P.kb0 + P.kb1;
+    int kb = kb_first + j;       // wave-uniform
+    if (kb >= total) kb = total - 1;
+    const char *base = kb < P.kb0 ? src0 + (size_t)kb * 4096 : src1 + (size_t)(kb - P.kb0) * 4096;
+    const f32x4 v = load16_s(base, c.voff[q], q * 1024);
+    b[j][4 * q + 0] = v.x; b[j][4 * q + 1] = v.y; b[j][4 * q + 2] = v.z; b[j][4 * q + 3] = v.w;
+}
+
 // One pass over the current tile.  DX: the reverse-chain flavour (ReLU masks from the record, density-row init).
 // pr0..pr2 carry the fc_out partial dot products across the passes of fc_9; `sig` the density pre-activation.
 template <int NFB, bool DX>
@@ -465,7 +478,15 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
             const unsigned long long la = LT_NOW();
             const char *w = c.lds + pipe.acquire();
             lt_acq += LT_NOW() - la;
-            if (pr + 1 < pairs) load_b_pair<KPC>(bB, P, (pr + 1) * 2 * KPC, src0, src1, c);
+            // the next pair's operands are fetched from inside this pair's MFMA groups, one 16-byte load per 32 / (8 KPC)
+            // groups -- in the 8-block passes (wide layers: many pairs; past the pass's end the eight loads re-read its
+            // last block and are never multiplied: a branch per load, or a second flavour of the MFMA loop, costs more).
+            // Narrow passes are one or two pairs long: they fetch in front of the MFMAs, and only what exists.
+            auto next_b = [&](int g, int groups) {
+                constexpr int NL = 8 * KPC;
+                if (NFB == 8 && g % (groups / NL) == 0) load_b_one<KPC>(bB, P, (pr + 1) * 2 * KPC, src0, src1, c, g / (groups / NL));
+            };
+            if (NFB < 8 && pr + 1 < pairs) load_b_pair<KPC>(bB, P, (pr + 1) * 2 * KPC, src0, src1, c);
             if (masked && pr + 1 >= pairs) {
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) {
@@ -478,7 +499,7 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
                 }
             }
             if (!DX && P.side == SIDE_DENSITY) density(bA, pr * 2 * KPC);
-            mma_slots<NFB, KPC, 0, 16>(acc, bA, w, c.offq, &pipe);
+            mma_slots<NFB, KPC, 0, 16, false>(acc, bA, w, c.offq, &pipe, next_b);
             if (2 * pr + 1 < chunks) mma_slots<NFB, KPC>(acc, bA + KPC, w + CHUNK_BYTES, c.offq);
             pipe.issue_done();
         }
@@ -486,7 +507,11 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
             const unsigned long long la = LT_NOW();
             const char *w = c.lds + pipe.acquire();
             lt_acq += LT_NOW() - la;
-            if (pr + 2 < pairs) load_b_pair<KPC>(bA, P, (pr + 2) * 2 * KPC, src0, src1, c);
+            auto next_b = [&](int g, int groups) {
+                constexpr int NL = 8 * KPC;
+                if (NFB == 8 && g % (groups / NL) == 0) load_b_one<KPC>(bA, P, (pr + 2) * 2 * KPC, src0, src1, c, g / (groups / NL));
+            };
+            if (NFB < 8 && pr + 2 < pairs) load_b_pair<KPC>(bA, P, (pr + 2) * 2 * KPC, src0, src1, c);
             if (masked && pr + 2 >= pairs) {
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) {
@@ -499,7 +524,7 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
                 }
             }
             if (!DX && P.side == SIDE_DENSITY) density(bB, (pr + 1) * 2 * KPC);
-            mma_slots<NFB, KPC, 0, 16>(acc, bB, w, c.offq, &pipe);
+            mma_slots<NFB, KPC, 0, 16, false>(acc, bB, w, c.offq, &pipe, next_b);
             if (2 * pr + 3 < chunks) mma_slots<NFB, KPC>(acc, bB + KPC, w + CHUNK_BYTES, c.offq);
             pipe.issue_done();
         }
