@@ -127,6 +127,16 @@ struct Pass {
     __host__ __device__ int pairs() const { return (chunks() + 1) / 2; }
 };
 
+// every field of a Pass, in one place: the persistent kernel tabulates its program in LDS once (one lane per pass) and
+// fetches a pass with one LDS read + one v_readlane per field (the scalar evaluation of fwd_pass / dx_pass cost 1.3-3.7 k
+// cycles per pass: scripts/timeline_layered.py)
+#define PASS_FIELDS(X) X(nfb) X(blocks) X(kb0) X(kb1) X(src_buf0) X(src_buf1) X(src_off0) X(src_off1) X(src_w0) X(src_w1) \
+    X(dst_buf) X(dst_off) X(dst_w) X(dst_fb0) X(mask_off) X(init) X(init_off) X(relu) X(side) X(first) X(last) X(transposed) \
+    X(layer0) X(layer1) X(row0) X(rows_valid) X(col00) X(col01) X(cols_valid0) X(cols_valid1)
+constexpr int PASS_ROW = 32;           // ints per tabulated pass (30 fields: one per lane of half a wavefront)
+constexpr int PASS_TABLE_MAX = 128;    // passes the LDS table holds (feat_dim <= 2048); longer programs are evaluated on the fly
+static_assert(sizeof(Pass) == 30 * sizeof(int), "PASS_FIELDS must name every field of Pass");
+
 __host__ __device__ inline int pass_nfb(int blocks) { return blocks > 4 ? 8 : blocks > 2 ? 4 : 2; }
 
 // Forward program: layer by layer (nerf.py:102-119), each layer in passes of <= 8 output blocks.
@@ -600,6 +610,18 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
     pipe.lds_wave = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 8192u;
     pipe.issued = 0; pipe.issue_pos = 0; pipe.consumed = 0;
     pipe.n_pairs = a.n_pairs; pipe.skip_mask = 0;
+    // the pass program, tabulated behind the ring: thread p evaluates pass p once
+    int *ptab = reinterpret_cast<int *>(lds + RING_SLOTS * CHUNK_BYTES);
+    // (the forward only: A/B on one box, the reverse chain came out 1-2.5 % SLOWER with the table although its pass
+    // boundaries shrank by 1 k cycles in the timeline -- its scalar program overlaps the mask loads' latency)
+    const bool tabulated = !DX && a.n_passes <= PASS_TABLE_MAX;
+    if (tabulated && tid < a.n_passes) {
+        const Pass P = DX ? dx_pass(a.D, a.inputs, tid) : fwd_pass(a.D, tid);
+        int k = 0;
+#define X(f) ptab[tid * PASS_ROW + k++] = P.f;
+        PASS_FIELDS(X)
+#undef X
+    }
     __syncthreads();
     pipe.issue();
 
@@ -658,7 +680,16 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
         }
         for (int p = 0; p < a.n_passes; ++p) {
             const unsigned long long lp = LT_NOW();
-            const Pass P = DX ? dx_pass(a.D, a.inputs, p) : fwd_pass(a.D, p);
+            Pass P;
+            if (tabulated) {
+                const int v = ptab[p * PASS_ROW + (lane & 31)];
+                int k = 0;
+#define X(f) P.f = __builtin_amdgcn_readlane(v, k++);
+                PASS_FIELDS(X)
+#undef X
+            } else {
+                P = DX ? dx_pass(a.D, a.inputs, p) : fwd_pass(a.D, p);
+            }
             // (the stamp must follow the program: a scalar of it orders the reads)
             LT_ADD(5, LT_NOW() - lp + (unsigned long long)(P.nfb & 0));
             if (P.nfb == 8) run_pass<8, DX>(P, a, c, pipe, pr0, pr1, pr2, sig, dsig);
@@ -1246,12 +1277,13 @@ extern "C" __attribute__((visibility("default"))) int nerf_debug_layered_timelin
 int launch_program(bool dx, const WideArgs &a, hipStream_t s) {
     auto kern = dx ? layered_kernel<true> : layered_kernel<false>;
     static nerf::DeviceMask configured[2] = {{0}, {0}};
-    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), RING_SLOTS * CHUNK_BYTES, configured[dx],
+    constexpr int GEN_LDS = RING_SLOTS * CHUNK_BYTES + PASS_TABLE_MAX * PASS_ROW * 4;   // ring + the tabulated pass program
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), GEN_LDS, configured[dx],
                                           "nerf_mlp_layered: LDS attribute"))
         return rc;
     const int64_t ntiles = a.MP / TILE_SAMPLES;
     const int cus = nerf::device_cus();
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(256), RING_SLOTS * CHUNK_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(256), GEN_LDS, s, a);
     return nerf::check_launch(dx ? "nerf_mlp_layered_backward: reverse chain" : "nerf_mlp_layered_forward");
 }
 
