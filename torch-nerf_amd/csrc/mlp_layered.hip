@@ -13,15 +13,16 @@
 //    branches and no address arithmetic in the k-loop (the first version of this file: per-element bounds-checked
 //    scalar staging loads, 64 x 64 x 16 tiles, one launch per layer: 0.18-0.46 of the MFMA peak)
 //  * a layer is cut into PASSES of <= 8 output blocks (256 features = 128 accumulator registers); the B operand of a
-//    pass streams through registers one pair (64 KiB of weights) ahead, as asm-issued loads the pair's own
-//    s_waitcnt vmcnt(0) covers
+//    pass streams through registers one pair (64 KiB of weights) ahead (compiler-counted loads; in the eight-block
+//    passes they ride between the MFMA groups of the pair in front of them)
 //  * bias = initial accumulator, ReLU / the ReLU mask of the reverse chain in the epilogue, both torch.cat
 //    (nerf.py:108, :116) = a pass with two source planes; the density row and fc_out (+ sigmoid) are vector side jobs
 //  * dW = the dW GEMM kernel of mlp_backward.hip over the same planes (nerf::run_dw_items), thin rows by a vector kernel
 // Padded widths (multiples of 32) carry exact zeros, so they add nothing to any sum.
 //
-// The pass programs are pure functions of the widths (fwd_pass / dx_pass, __host__ __device__): the kernels
-// evaluate them on the scalar unit at every pass boundary, the pack kernel evaluates them per pair.
+// The pass programs are pure functions of the widths (fwd_pass / dx_pass, __host__ __device__): the reverse chain
+// evaluates them on the scalar unit at every pass boundary, the forward tabulates its program in LDS once per launch,
+// the pack kernel evaluates them per slot.
 #include <type_traits>
 #include <vector>
 
