@@ -178,7 +178,8 @@ def test_full_tensor_vs_oracle(oracle, golden, tag, M):
 @pytest.mark.parametrize("dims,M", [((21, 15, 128), 700), ((63, 27, 128), 2049), ((75, 27, 100), 513), ((96, 32, 128), 256),
                                     ((75, 27, 256), 515), ((93, 27, 256), 130), ((27, 15, 230), 257),
                                     ((63, 27, 512), 300), ((40, 40, 160), 333), ((63, 27, 96), 129),
-                                    ((63, 27, 64), 700), ((75, 27, 40), 257), ((21, 15, 50), 130), ((75, 39, 64), 300)])
+                                    ((63, 27, 64), 700), ((75, 27, 40), 257), ((21, 15, 50), 130), ((75, 39, 64), 300),
+                                    ((63, 27, 64), 1), ((63, 27, 128), 31), ((63, 27, 512), 33), ((75, 27, 256), 2)])
 def test_layered_family_any_widths_vs_oracle(oracle, dims, M):
     """Widths the fixtures do not hold, every element against the CPU oracle under the kernel's own ReLU decisions:
     the register-resident kernels (feat_dim 33..64 and 97..128 with two sample blocks per wavefront, feat_dim 225..256 with
