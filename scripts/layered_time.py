@@ -15,7 +15,7 @@ def t(fn, window_ms=120.0):   # mean over ~window_ms of back-to-back calls (as b
     fn(); torch.cuda.synchronize()
     return run(max(3, min(200, int(window_ms / max(run(2), 1e-3)))))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-NETS = ((63, 27, 256), (75, 27, 256), (63, 27, 128), (63, 27, 64), (75, 39, 64), (40, 40, 160), (63, 27, 512))
+NETS = ((63, 27, 256), (75, 27, 256), (99, 27, 256), (63, 27, 128), (63, 27, 64), (75, 39, 64), (40, 40, 160), (63, 27, 512))
 if len(sys.argv) > 2:   # e.g. "128,512": feat_dims to run (profiling passes)
     NETS = tuple(n for n in NETS if str(n[2]) in sys.argv[2].split(",") or f"{n[0]}x{n[2]}" in sys.argv[2].split(","))
 PEAK = 157.3

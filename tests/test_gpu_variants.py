@@ -179,11 +179,12 @@ def test_full_tensor_vs_oracle(oracle, golden, tag, M):
                                     ((75, 27, 256), 515), ((93, 27, 256), 130), ((27, 15, 230), 257),
                                     ((63, 27, 512), 300), ((40, 40, 160), 333), ((63, 27, 96), 129),
                                     ((63, 27, 64), 700), ((75, 27, 40), 257), ((21, 15, 50), 130), ((75, 39, 64), 300),
-                                    ((63, 27, 64), 1), ((63, 27, 128), 31), ((63, 27, 512), 33), ((75, 27, 256), 2)])
+                                    ((63, 27, 64), 1), ((63, 27, 128), 31), ((63, 27, 512), 33), ((75, 27, 256), 2),
+                                    ((99, 27, 256), 300), ((99, 27, 64), 515), ((99, 27, 128), 129)])
 def test_layered_family_any_widths_vs_oracle(oracle, dims, M):
     """Widths the fixtures do not hold, every element against the CPU oracle under the kernel's own ReLU decisions:
     the register-resident kernels (feat_dim 33..64 and 97..128 with two sample blocks per wavefront, feat_dim 225..256 with
-    pos_dim 65..96 = coord_encode_level 12..15 -- one, two and three position blocks, ragged feat_dim 100 / 230) and
+    pos_dim 65..128 = coord_encode_level 12..16 -- one to four position blocks, ragged feat_dim 100 / 230) and
     the general plane-parked kernel (feat_dim 512: two passes per layer; 160: a ragged
     pass; view_dir_dim 40: two direction blocks), forward, parameter gradients and input gradients."""
     from helpers import assert_grads_match_given_masks, layered_masks

@@ -716,8 +716,10 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
 constexpr int REG_LDS = RING_SLOTS * CHUNK_BYTES + 16384;   // ring + the constant block (<= 4096 floats)
 
 __host__ __device__ inline bool reg_ok(const Dims &D) {
+    // (four position blocks -- coord_encode_level 16: pos_dim 99 -- where the encoded position is one sample block or
+    // the network is narrow; with two sample blocks of 128 features its 128 registers do not fit)
     return ((D.Fp == 64 && D.Hp == 32) || (D.Fp == 128 && D.Hp == 64) || (D.Fp == 256 && D.Hp == 128)) && D.Dp == 32 &&
-           D.Pp <= 96 && D.c_floats() <= 4096;
+           D.Pp <= (D.Fp == 128 ? 96 : 128) && D.c_floats() <= 4096;
 }
 
 template <int N, class F> __device__ __forceinline__ void static_for(F f) {     // f(integral_constant<0>) .. f(<N-1>)
@@ -1121,10 +1123,12 @@ int launch_reg_fwd(bool record, const WideArgs &a, hipStream_t s) {
 int launch_reg_forward(bool record, const WideArgs &a, hipStream_t s) {
     const int pb = a.D.Pp / 32;
     if (a.D.Fp == 64)
-        return pb == 1 ? launch_reg_fwd<2, 2, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<2, 2, 2>(record, a, s) : launch_reg_fwd<2, 2, 3>(record, a, s);
+        return pb == 1 ? launch_reg_fwd<2, 2, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<2, 2, 2>(record, a, s)
+             : pb == 3 ? launch_reg_fwd<2, 2, 3>(record, a, s) : launch_reg_fwd<2, 2, 4>(record, a, s);
     if (a.D.Fp == 128)
         return pb == 1 ? launch_reg_fwd<2, 4, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<2, 4, 2>(record, a, s) : launch_reg_fwd<2, 4, 3>(record, a, s);
-    return pb == 1 ? launch_reg_fwd<1, 8, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<1, 8, 2>(record, a, s) : launch_reg_fwd<1, 8, 3>(record, a, s);
+    return pb == 1 ? launch_reg_fwd<1, 8, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<1, 8, 2>(record, a, s)
+         : pb == 3 ? launch_reg_fwd<1, 8, 3>(record, a, s) : launch_reg_fwd<1, 8, 4>(record, a, s);
 }
 
 template <int NFB, int PB>
@@ -1142,7 +1146,8 @@ int launch_narrow_dx_pb(bool ig, const WideArgs &a, hipStream_t s) {
 int launch_narrow_dx(bool ig, const WideArgs &a, hipStream_t s) {
     const int pb = a.D.Pp / 32;
     if (a.D.Fp == 64)
-        return pb == 1 ? launch_narrow_dx_pb<2, 1>(ig, a, s) : pb == 2 ? launch_narrow_dx_pb<2, 2>(ig, a, s) : launch_narrow_dx_pb<2, 3>(ig, a, s);
+        return pb == 1 ? launch_narrow_dx_pb<2, 1>(ig, a, s) : pb == 2 ? launch_narrow_dx_pb<2, 2>(ig, a, s)
+             : pb == 3 ? launch_narrow_dx_pb<2, 3>(ig, a, s) : launch_narrow_dx_pb<2, 4>(ig, a, s);
     return pb == 1 ? launch_narrow_dx_pb<4, 1>(ig, a, s) : pb == 2 ? launch_narrow_dx_pb<4, 2>(ig, a, s) : launch_narrow_dx_pb<4, 3>(ig, a, s);
 }
 
