@@ -1175,14 +1175,15 @@ __global__ __launch_bounds__(64) void layered_thin_kernel(const Dims D, const fl
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0;
-    // four tiles per trip: their 16 loads are in flight together (one tile at a time, each wavefront sat through a
+    constexpr int TPT = 8;
+    // TPT tiles per trip: their 4 TPT loads are in flight together (one tile at a time, each wavefront sat through a
     // loaded HBM round trip per 4 KiB: 2.4 TB/s with 12 wavefronts per CU)
-    for (int64_t t = t0; t < t1; t += 4) {
-        f32x16 x[4];
-        float g1[4];
-        f32x4 g4[4];
+    for (int64_t t = t0; t < t1; t += TPT) {
+        f32x16 x[TPT];
+        float g1[TPT];
+        f32x4 g4[TPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TPT; ++j) {
             const int64_t tj = t + j < t1 ? t + j : t1 - 1;       // past the end: a re-read with zero weights
             const int64_t m = tj * 32 + i;
             x[j] = load_block(plane + tj * 32 * width, fb, i, h);
@@ -1193,7 +1194,7 @@ __global__ __launch_bounds__(64) void layered_thin_kernel(const Dims D, const fl
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TPT; ++j) {
             if (is_h7) {
                 const double g = (double)g1[j];
                 if (h == 0) ssum[0] += g;
