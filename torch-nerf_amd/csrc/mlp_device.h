@@ -212,10 +212,10 @@ __device__ __forceinline__ void lds_fragments_ready() {
 // out every ~190 cycles (four wavefronts share the CU's ~16 B / clock store path: scripts/timeline_layered.py), and at
 // the seam nothing hides that: 32 stores = 6 k cycles of a 65 k-cycle layer.  The blocks stored must stay untouched
 // until the last store has been issued (they are the B operands of the layer being multiplied: they do).
-// AGPR_DATA: the asm store takes its data from accumulator registers -- where a kernel's VGPR half is full (the layered
-// register-resident kernels) the four-register copy a "v" operand may need spills; the AGPR half has room.
-template <bool AGPR_DATA>
-struct PlaneStoreT {
+// (The data operand is a VGPR: where the allocator keeps some of the stored blocks in AGPRs -- the layered family's
+// register-resident record forward -- every store needs a four-register copy; an "a" operand moves the problem to the
+// blocks that sit in VGPRs.  Those kernels keep their stores at the seam.)
+struct PlaneStore {
     uint64_t tile;         // address of this wavefront's 32-sample tile of the plane (wave-uniform: SGPR pair)
     unsigned unit16;       // (2 i + h) << 4
     const f32x16 *blk;
@@ -233,16 +233,10 @@ struct PlaneStoreT {
         const f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
         // (s_nop 4 in front: the scalar base may come straight out of a v_readfirstlane / SALU add -- see save_plane();
         // s_nop 1 behind: wide-store data hazard, inside the statement)
-        if (AGPR_DATA)
-            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
-                         : : "v"(unit16 ^ (32u * q)), "a"(v), "s"(tile + (uint64_t)fb * 4096u), "n"(q * 1024) : "memory");
-        else
-            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
-                         : : "v"(unit16 ^ (32u * q)), "v"(v), "s"(tile + (uint64_t)fb * 4096u), "n"(q * 1024) : "memory");
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
+                     : : "v"(unit16 ^ (32u * q)), "v"(v), "s"(tile + (uint64_t)fb * 4096u), "n"(q * 1024) : "memory");
     }
 };
-using PlaneStore = PlaneStoreT<false>;
-using PlaneStoreA = PlaneStoreT<true>;
 
 // N_STORES > 0: stores FIRST_STORE .. FIRST_STORE + N_STORES - 1 of `st` are issued between the groups of this chunk too.
 template <int NFB, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false, int N_STORES = 0>
@@ -329,9 +323,9 @@ __device__ __forceinline__ void mma_slots(f32x16 *acc, const f32x16 *b, const ch
 // well (PlaneStore): store s belongs to sample block s / SPS (st[s / SPS]) and is its store s % SPS.  `first_store` is a
 // constant after unrolling.
 template <int NFB, int NKB, int STRIDE, int FIRST_PIECE = 0, int N_PIECES = 0, bool FRESH = false, int NSB = 2,
-          int N_STORES = 0, int SPS = 1, int S_TOTAL = 0, class BSel, class St = PlaneStore>
+          int N_STORES = 0, int SPS = 1, int S_TOTAL = 0, class BSel>
 __device__ __forceinline__ void mma_slots2(f32x16 *acc0, f32x16 *acc1, BSel bsel, const char *chunk, const int (&offq)[4],
-                                           const Pipe *pipe = nullptr, const St *st = nullptr, int first_store = 0) {
+                                           const Pipe *pipe = nullptr, const PlaneStore *st = nullptr, int first_store = 0) {
     static_assert(NFB <= STRIDE && STRIDE * NKB <= 8, "a chunk holds eight slots");
     constexpr int GROUPS = 4 * NFB * NKB;
     const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)chunk;
