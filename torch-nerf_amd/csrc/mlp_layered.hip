@@ -67,13 +67,18 @@ struct Dims {
     int Pp, Dp, Fp, Hp;          // plane widths: padded to whole 32-feature blocks
     int64_t w[11], b[11], total; // flat parameter blob, state_dict order
     int in[11], out[11];
-    __host__ __device__ int recw() const { return Pp + Dp + 9 * Fp + Hp; }          // record floats per sample
+    __host__ __device__ int mw() const { return (Fp / 32 + 1) / 2; }               // ReLU-mask dwords per (sample, lane half) and layer
+    __host__ __device__ int recw() const { return Pp + Dp + 9 * Fp + 18 * mw() + Hp; }   // record floats per sample
     __host__ __device__ int gradw() const { return 9 * Fp + Hp + 8 + Pp + Dp; }     // gradient planes, floats per sample
     // record planes, float offset per sample (x MP)
     __host__ __device__ int r_pe() const { return 0; }
     __host__ __device__ int r_de() const { return Pp; }
     __host__ __device__ int r_h(int l) const { return Pp + Dp + l * Fp; }           // h0..h7 (l = 8: y8)
-    __host__ __device__ int r_h9() const { return Pp + Dp + 9 * Fp; }
+    // ReLU decisions as BIT planes (l = 0..7: h_l > 0; 8: h9 > 0), what the reverse chain reads instead of the activation
+    // planes: dword (2 m + h) mw + fb / 2 of plane l holds, for lane half h of sample m, bit 16 (fb & 1) + r = register r
+    // of feature block fb (the fused family's save_mask / masked layout, mlp_device.h)
+    __host__ __device__ int r_mask(int l) const { return Pp + Dp + 9 * Fp + 2 * mw() * l; }
+    __host__ __device__ int r_h9() const { return Pp + Dp + 9 * Fp + 18 * mw(); }
     // gradient planes
     __host__ __device__ int g_dy(int l) const { return l * Fp; }                    // dY0..dY7, dY8
     __host__ __device__ int g_dy9() const { return 9 * Fp; }
@@ -115,7 +120,8 @@ struct Pass {
     int kb0, kb1;            // k-blocks of the two sources (torch.cat); kb1 = 0: one source
     int src_buf0, src_buf1, src_off0, src_off1, src_w0, src_w1;   // (scalars, not arrays: hipcc parks a struct's arrays in scratch)
     int dst_buf, dst_off, dst_w, dst_fb0;
-    int mask_off;            // record plane whose sign masks the result (reverse chain), -1: none; same window as dst
+    int mask_off;            // bit plane (r_mask) -- reverse chain: the one that masks the result, forward: the one the
+                             // pass's ReLU decisions are written to; -1: none.  Words dst_fb0 / 2 .. of every (sample, half)
     int init, init_off;      // INIT_*: constant-block offset of the bias window / the density row
     int relu;
     int side;
@@ -154,7 +160,7 @@ __host__ __device__ inline Pass fwd_pass(const Dims &D, int idx) {
     Pass P = {};
     P.blocks = nblk - 8 * j < 8 ? nblk - 8 * j : 8;
     P.nfb = pass_nfb(P.blocks);
-    P.dst_buf = 0; P.dst_fb0 = 8 * j; P.mask_off = -1;
+    P.dst_buf = 0; P.dst_fb0 = 8 * j; P.mask_off = l == 9 ? D.r_mask(8) : l == 8 ? -1 : D.r_mask(l);
     P.dst_off = l == 9 ? D.r_h9() : D.r_h(l); P.dst_w = l == 9 ? D.Hp : D.Fp;
     P.init = INIT_BIAS; P.init_off = D.c_bias(l) + 256 * j;
     P.relu = l != 8;                                          // fc_8 has no ReLU (nerf.py:113)
@@ -220,7 +226,7 @@ __host__ __device__ inline Pass dx_pass(const Dims &D, int inputs, int idx) {
         P.row0 = l == 8 ? 1 : 0; P.rows_valid = D.F;
         P.col00 = l == 5 ? D.E_p : 0; P.cols_valid0 = D.F;
         P.dst_off = D.g_dy(l - 1); P.dst_w = D.Fp;
-        P.mask_off = D.r_h(l - 1);
+        P.mask_off = D.r_mask(l - 1);
         if (l == 8) { P.init = INIT_DENSITY; P.init_off = D.c_w8row() + 256 * j; }
     }
     return P;
@@ -349,6 +355,7 @@ struct WideArgs {
     float *rec, *grad;       // buffer 0 / buffer 1 (plane = buffer + offset * MP)
     int64_t M, MP;
     int n_passes, n_pairs, inputs;
+    int record;                          // forward: a backward will read this record (ReLU bit planes are written)
     float *sigma, *rgb;                  // forward outputs
     const float *sigma_in, *rgb_in, *g_sigma, *g_rgb;   // reverse chain inputs
 };
@@ -376,6 +383,32 @@ struct Ctx {
 // this wavefront's 32-sample tile of a plane: base + (row0 / 32) * (32 * width floats)
 __device__ __forceinline__ const char *tile_of(const float *buf, int off, int width, int64_t MP, int64_t row0) {
     return reinterpret_cast<const char *>(buf + (int64_t)off * MP + row0 * width);
+}
+
+// ReLU decisions of NFB blocks of this lane -> NFB / 2 dwords (bit 16 (fb & 1) + r of word fb / 2 = register r of block fb
+// is > 0, i.e. its bit pattern is not 0 after the ReLU): two vector instructions per value (mlp_device.h: save_mask)
+template <int NFB>
+__device__ __forceinline__ void pack_mask_words(const f32x16 *blk, unsigned (&w)[(NFB + 1) / 2]) {
+#pragma unroll
+    for (int k = 0; k < (NFB + 1) / 2; ++k) w[k] = 0u;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned t;
+            asm("v_min_u32 %0, 1, %1" : "=v"(t) : "v"(blk[fb][r]));
+            w[fb >> 1] |= t << (16 * (fb & 1) + r);
+        }
+}
+// v where bit (fb, r) of the mask words is set, else +0 (mlp_backward.hip: masked)
+__device__ __forceinline__ float keep_bit(unsigned word, int bit, float v) {
+    int keep;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(word), "n"(bit));   // the bit, sign-extended to 0 / ~0 (`bit`: a constant after unrolling)
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
+}
+// this lane's mask words: plane + ((2 m + h) mw + w0) dwords
+__device__ __forceinline__ unsigned *mask_words_of(float *rec, int mask_off, int64_t MP, int64_t m, int h, int mw, int w0) {
+    return reinterpret_cast<unsigned *>(rec + (int64_t)mask_off * MP) + (2 * m + h) * mw + w0;
 }
 
 // B operands of one PAIR of the pass (2 * KPC k-blocks starting at k-block kb_first).  k-blocks past the pass's end
@@ -456,15 +489,19 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
     }
     if (!DX && P.side == SIDE_DENSITY) sig = 0.0f;
 
-    f32x16 mk[NFB];          // DX: the forward activations whose sign masks this pass's result
+    // DX: the ReLU decisions that mask this pass's result, NFB / 2 dwords from the record's bit planes (an unmasked stage
+    // keeps everything: all ones, and the epilogue below has no branch).  Words past the plane's own (a ragged last
+    // pass) re-read its last word: they mask blocks nothing stores.
+    constexpr int NW = NFB / 2;
+    unsigned mkb[NW];
     const bool masked = DX && P.mask_off >= 0;
-    if (DX && !masked) {     // an unmasked stage keeps everything: the epilogue below has no branch
+    const int mwords = a.D.mw(), w0 = P.dst_fb0 / 2;
+    const int nw_valid = mwords - w0 < NW ? mwords - w0 : NW;     // wave-uniform
+    if (DX) {
+        const unsigned *mp = masked ? mask_words_of(a.rec, P.mask_off, a.MP, c.m, c.h, mwords, w0) : nullptr;
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mk[fb][r] = 1.0f;
+        for (int k = 0; k < NW; ++k) mkb[k] = masked ? mp[k < nw_valid ? k : nw_valid - 1] : 0xffffffffu;
     }
-    const char *mtile = masked ? tile_of(a.rec, P.mask_off, P.dst_w, a.MP, c.row0) + (size_t)P.dst_fb0 * 4096 : nullptr;
 
     // the density row of fc_8 rides on the B operands streaming by (nerf.py:113-115): sigma' = W8[0, :] . h7 + b
     auto density = [&](const f32x16 (&b)[2 * KPC], int kb_first) {
@@ -498,17 +535,6 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
                 if (NFB == 8 && g % (groups / NL) == 0) load_b_one<KPC>(bB, P, (pr + 1) * 2 * KPC, src0, src1, c, g / (groups / NL));
             };
             if (NFB < 8 && pr + 1 < pairs) load_b_pair<KPC>(bB, P, (pr + 1) * 2 * KPC, src0, src1, c);
-            if (masked && pr + 1 >= pairs) {
-#pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) {
-                    const char *mb = mtile + (fb < P.blocks ? fb : 0) * 4096;    // (blocks the pass does not have: any finite plane)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = load16_s(mb, c.voff[q], q * 1024);
-                        mk[fb][4 * q + 0] = v.x; mk[fb][4 * q + 1] = v.y; mk[fb][4 * q + 2] = v.z; mk[fb][4 * q + 3] = v.w;
-                    }
-                }
-            }
             if (!DX && P.side == SIDE_DENSITY) density(bA, pr * 2 * KPC);
             mma_slots<NFB, KPC, 0, 16, false>(acc, bA, w, c.offq, &pipe, next_b);
             if (2 * pr + 1 < chunks) mma_slots<NFB, KPC>(acc, bA + KPC, w + CHUNK_BYTES, c.offq);
@@ -523,17 +549,6 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
                 if (NFB == 8 && g % (groups / NL) == 0) load_b_one<KPC>(bA, P, (pr + 2) * 2 * KPC, src0, src1, c, g / (groups / NL));
             };
             if (NFB < 8 && pr + 2 < pairs) load_b_pair<KPC>(bA, P, (pr + 2) * 2 * KPC, src0, src1, c);
-            if (masked && pr + 2 >= pairs) {
-#pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) {
-                    const char *mb = mtile + (fb < P.blocks ? fb : 0) * 4096;    // (blocks the pass does not have: any finite plane)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = load16_s(mb, c.voff[q], q * 1024);
-                        mk[fb][4 * q + 0] = v.x; mk[fb][4 * q + 1] = v.y; mk[fb][4 * q + 2] = v.z; mk[fb][4 * q + 3] = v.w;
-                    }
-                }
-            }
             if (!DX && P.side == SIDE_DENSITY) density(bB, (pr + 1) * 2 * KPC);
             mma_slots<NFB, KPC, 0, 16, false>(acc, bB, w, c.offq, &pipe, next_b);
             if (2 * pr + 3 < chunks) mma_slots<NFB, KPC>(acc, bB + KPC, w + CHUNK_BYTES, c.offq);
@@ -552,9 +567,21 @@ __device__ __forceinline__ void run_pass(const Pass &P, const WideArgs &a, const
         for (int r = 0; r < 16; ++r) {
             float v = acc[fb][r];
             if (!DX) asm("v_max_f32 %0, %1, %2" : "=v"(v) : "s"(floor), "v"(acc[fb][r]));
-            else v = mk[fb][r] > 0.0f ? v : 0.0f;
+            else v = keep_bit(mkb[fb >> 1], 16 * (fb & 1) + r, v);
             acc[fb][r] = v;
         }
+    if (!DX && a.record && P.mask_off >= 0) {   // the ReLU decisions of this pass, for the reverse chain (bit planes)
+        unsigned w[NW];
+        pack_mask_words<NFB>(acc, w);
+        unsigned *mp = mask_words_of(a.rec, P.mask_off, a.MP, c.m, c.h, mwords, w0);
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            if (k < nw_valid) mp[k] = w[k];
+        // (h9 is half as wide as the planes are strided for: its unused words are written too -- every byte of a record is
+        // a function of the inputs, tests/test_gpu_determinism.py compares them all)
+        if (P.last)
+            for (int k = w0 + nw_valid; k < mwords; ++k) mp[k - w0] = 0u;
+    }
     float *dbuf = P.dst_buf ? a.grad : a.rec;
     float *dplane = dbuf + (int64_t)P.dst_off * a.MP + (int64_t)P.dst_fb0 * 1024;
     // (block counts are wave-uniform: whole store groups are skipped for blocks the plane does not have)
@@ -659,9 +686,10 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
                 a.grad[(int64_t)a.D.g_dsig() * a.MP + c.m] = dsig;
             }
             const float *wout = a.consts + a.D.c_wout();
-            const float *h9 = a.rec + (int64_t)a.D.r_h9() * a.MP + c.row0 * a.D.Hp;
+            const unsigned *m9 = mask_words_of(a.rec, a.D.r_mask(8), a.MP, c.m, c.h, a.D.mw(), 0);
             float *d9 = a.grad + (int64_t)a.D.g_dy9() * a.MP;
             for (int fb = 0; fb < a.D.Hp / 32; ++fb) {
+                const unsigned bits9 = (m9[fb >> 1] >> (16 * (fb & 1))) & 0xffffu;     // [h9 > 0] of this block's 16 registers
                 f32x16 x;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -669,11 +697,10 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
                     const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wout + k0);
                     const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wout + a.D.Hp + k0);
                     const f32x4 w2 = *reinterpret_cast<const f32x4 *>(wout + 2 * a.D.Hp + k0);
-                    const f32x4 hv = *reinterpret_cast<const f32x4 *>(h9 + (fb * 4 + q) * 256 + 4 * ((2 * c.i + c.h) ^ (2 * q)));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v = fmaf(w2[j], gy[2], fmaf(w1[j], gy[1], w0[j] * gy[0]));
-                        x[4 * q + j] = hv[j] > 0.0f ? v : 0.0f;
+                        x[4 * q + j] = ((bits9 >> (4 * q + j)) & 1u) ? v : 0.0f;
                     }
                 }
                 save_plane<1, true>(d9 + fb * 1024, a.D.Hp, c.m, c.h, &x);
@@ -844,7 +871,14 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
             // every record variant and 3-5 % slower; at the seam the dead accumulators lend the registers)
             if (RECORD) {
 #pragma unroll
-                for (int sb = 0; sb < NSB; ++sb) save_plane<NFB, true>(plane(D.r_h(l - 1)), FP, m[sb], h, act[sb]);
+                for (int sb = 0; sb < NSB; ++sb) {
+                    save_plane<NFB, true>(plane(D.r_h(l - 1)), FP, m[sb], h, act[sb]);
+                    unsigned w[NFB / 2];          // [h(l-1) > 0] as bits, for the reverse chain
+                    pack_mask_words<NFB>(act[sb], w);
+                    unsigned *mp = mask_words_of(a.rec, D.r_mask(l - 1), MP, m[sb], h, NFB / 2, 0);
+#pragma unroll
+                    for (int k = 0; k < NFB / 2; ++k) mp[k] = w[k];
+                }
             }
             if (l == 8) {   // density row of fc_8
 #pragma unroll
@@ -893,7 +927,14 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
             for (int fb = 0; fb < HB; ++fb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a9[sb][fb][r] = relu1(a9[sb][fb][r]);
-            if (RECORD) save_plane<HB, true>(plane(D.r_h9()), HP, m[sb], h, a9[sb]);
+            if (RECORD) {
+                save_plane<HB, true>(plane(D.r_h9()), HP, m[sb], h, a9[sb]);
+                unsigned w[(HB + 1) / 2];
+                pack_mask_words<HB>(a9[sb], w);
+                unsigned *mp = mask_words_of(a.rec, D.r_mask(8), MP, m[sb], h, NFB / 2, 0);
+#pragma unroll
+                for (int k = 0; k < NFB / 2; ++k) mp[k] = k < (HB + 1) / 2 ? w[k < (HB + 1) / 2 ? k : 0] : 0u;   // (unused words: zeros)
+            }
             float s = sig[sb] + __shfl_xor(sig[sb], 32, WAVE);
             s = fmaxf(s + cb[D.c_scal()], 0.0f);                      // relu(x[:, 0]) (:115)
             float y[3];
@@ -910,14 +951,6 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// v where the forward activation was positive, else +0
-__device__ __forceinline__ f32x16 masked_by(const f32x16 &v, const f32x16 &act) {
-    f32x16 x;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = act[r] > 0.0f ? v[r] : 0.0f;
-    return x;
 }
 
 // The reverse chain of the narrow networks (NSB = 2): written out for its one geometry -- 128 accumulator + 128
@@ -949,7 +982,6 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
     pipe.issue();
     const Dims &D = a.D;
     const int64_t MP = a.MP;
-    auto rplane = [&](int off) { return a.rec + (int64_t)off * MP; };
     auto gplane = [&](int off) { return a.grad + (int64_t)off * MP; };
 
     for (int64_t tile = blockIdx.x; tile < MP / 256; tile += gridDim.x) {
@@ -977,10 +1009,11 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
                 *reinterpret_cast<f32x4 *>(gplane(D.g_gy()) + 4 * m[sb]) = g4;
                 gplane(D.g_dsig())[m[sb]] = dsig[sb];
             }
-            const float *h9t = rplane(D.r_h9()) + (row0 + 32 * sb) * HP;
+            unsigned b9[(HB + 1) / 2];      // [h9 > 0]
+#pragma unroll
+            for (int k = 0; k < (HB + 1) / 2; ++k) b9[k] = mask_words_of(a.rec, D.r_mask(8), MP, m[sb], h, NFB / 2, 0)[k];
 #pragma unroll
             for (int fb = 0; fb < HB; ++fb) {
-                const f32x16 hv = load_block(h9t, fb, i, h);
                 f32x16 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -991,11 +1024,13 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[4 * q + j] = fmaf(w2[j], gy[2], fmaf(w1[j], gy[1], w0[j] * gy[0]));
                 }
-                d9[sb][fb] = masked_by(v, hv);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d9[sb][fb][r] = keep_bit(b9[fb >> 1], 16 * (fb & 1) + r, v[r]);
             }
             save_plane<HB, true>(gplane(D.g_dy9()), HP, m[sb], h, d9[sb]);
         }
-        f32x16 acc[2][NFB], act[2][NFB], mk[2][NFB];
+        f32x16 acc[2][NFB], act[2][NFB];
+        unsigned mk[2][NFB / 2];        // the ReLU decisions of the next seam, from the record's bit planes
         auto D9 = [&](int sb, int kb) -> const f32x16 & { return d9[sb][kb]; };
         // ---- d y8[1:] = W9[:, :F]^T dY9
         {
@@ -1011,27 +1046,31 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
             save_plane<1, true>(gplane(D.g_gd()), 32, m[0], h, &gd[0]);
             save_plane<1, true>(gplane(D.g_gd()), 32, m[1], h, &gd[1]);
         }
-        // ReLU masks = the forward activations, fetched one stage ahead of the seam that applies them
+        // ReLU masks, fetched one stage ahead of the seam that applies them
+        auto load_masks = [&](int l) {
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
+            for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) mk[sb][fb] = load_block(rplane(D.r_h(7)) + (row0 + 32 * sb) * FP, fb, i, h);
-        __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < NFB / 2; ++k) mk[sb][k] = mask_words_of(a.rec, D.r_mask(l), MP, m[sb], h, NFB / 2, 0)[k];
+        };
+        auto apply_masks = [&](int sb) {
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[sb][fb][r] = keep_bit(mk[sb][fb >> 1], 16 * (fb & 1) + r, acc[sb][fb][r]);
+        };
+        load_masks(7);
         // ---- l = 8 .. 1: dY(l-1) = (W_l^T dY(l)) . [h(l-1) > 0]; the accumulators entering stage l hold dY(l) unmasked
         for (int l = 8; l >= 1; --l) {
             const char *w = lds + pipe.acquire();
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
+            for (int sb = 0; sb < 2; ++sb) {
+                if (l == 8) {
 #pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) act[sb][fb] = l == 8 ? acc[sb][fb] : masked_by(acc[sb][fb], mk[sb][fb]);
-            if (l < 8) {   // masks of the next seam: h(l-1)
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                    for (int fb = 0; fb < NFB; ++fb)
-                        mk[sb][fb] = load_block(rplane(D.r_h(l - 1)) + (row0 + 32 * sb) * FP, fb, i, h);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int fb = 0; fb < NFB; ++fb) act[sb][fb] = acc[sb][fb];
+                } else apply_masks(sb);
             }
+            if (l < 8) load_masks(l - 1);   // masks of the next seam: h(l-1)
             PlaneStore st[2];     // dY(l) leaves between the MFMA groups of the first chunk
             st[0].open(gplane(D.g_dy(l)), FP, m[0], h, act[0]);
             st[1].open(gplane(D.g_dy(l)), FP, m[1], h, act[1]);
@@ -1059,8 +1098,7 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
         // ---- dY0
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
-#pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) act[sb][fb] = masked_by(acc[sb][fb], mk[sb][fb]);
+            apply_masks(sb);
             save_plane<NFB, true>(gplane(D.g_dy(0)), FP, m[sb], h, act[sb]);
         }
         if (IG) {   // g_pos = W_in^T dY0 + W5[:, :E_p]^T dY5 (nerf.py:102, :108); dY5 back from its plane
@@ -1076,10 +1114,11 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
             };
             const char *w = lds + pipe.acquire();
             if constexpr (NFB == 2) {
-                reload(mk);        // (the mask registers are free by now)
-                auto Y5 = [&](int sb, int kb) -> const f32x16 & { return mk[sb][kb]; };
+                f32x16 y5[2][NFB];
+                reload(y5);
+                auto Y5 = [&](int sb, int kb) -> const f32x16 & { return y5[sb][kb]; };
                 if constexpr (PB <= 2) {   // pass of 2 blocks: one chunk = dY0's two k-blocks, then dY5's
-                    auto B = [&](int sb, int kb) -> const f32x16 & { return kb < 2 ? act[sb][kb < 2 ? kb : 0] : mk[sb][kb >= 2 ? kb - 2 : 0]; };
+                    auto B = [&](int sb, int kb) -> const f32x16 & { return kb < 2 ? act[sb][kb < 2 ? kb : 0] : y5[sb][kb >= 2 ? kb - 2 : 0]; };
                     mma_slots2<PB, 4, 2, 0, 16, true>(gp[0], gp[1], B, w, offq, &pipe);
                 } else {                   // pass of 4 blocks: two k-blocks per chunk
                     mma_slots2<PB, 2, 4, 0, 16, true>(gp[0], gp[1], A0, w, offq, &pipe);
@@ -1373,7 +1412,7 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
         WideArgs a = {};
         a.D = D; a.stream = reinterpret_cast<const char *>(fstream); a.consts = consts;
         a.rec = planes; a.grad = nullptr; a.M = rows; a.MP = MP;
-        a.n_passes = fwd_num_passes(D); a.n_pairs = pa.n_pairs; a.inputs = 0;
+        a.n_passes = fwd_num_passes(D); a.n_pairs = pa.n_pairs; a.inputs = 0; a.record = record_rows >= M;
         a.sigma = sigma + r0; a.rgb = rgb + 3 * r0;
         // networks that fit the register file: planes written only when the whole batch is recorded for a backward
         if (int rc = reg_ok(D) ? launch_reg_forward(record_rows >= M, a, s) : launch_program(false, a, s)) return rc;
