@@ -164,6 +164,8 @@ int nerf_mlp_backward(const nerf_net_t *net, const void *packed, const float *pa
  * g_pos (M,pos_dim) / g_view_dir (M,view_dir_dim), the gradients w.r.t. the encoded inputs.  No atomics: the
  * sample-axis reductions are split into fixed slices summed in a fixed order (bit-reproducible gradients).
  * workspace: nerf_mlp_layered_workspace_bytes(net, M).
+ * (The record also holds the ReLU decisions of h0..h7 and h9 as bit planes, between fc_8[1:] and h9: what the reverse
+ * chain reads.)
  * nerf_mlp_layered_plane: byte offset + padded width of a record plane (0 pos, 1 dir, 2..9 h0..h7, 10 fc_8[1:], 11 h9),
  * for tools and tests. */
 int64_t nerf_mlp_layered_record_bytes(const nerf_net_t *net, int64_t rows);

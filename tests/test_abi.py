@@ -48,7 +48,7 @@ def test_network_descriptions_choose_the_kernel_family():
         assert lib.nerf_mlp_path(n) == path, (lp, ld, inc, feat)
         assert lib.nerf_mlp_param_count(n) == synth.param_count(e_p, e_d, feat)
         assert (lib.nerf_mlp_packed_bytes(n) > 0) == (path == 0)      # the layered family packs inside its calls
-        # record = constant block + forward stream + 256 padded rows of planes (two inputs, h0..h7, fc_8[1:], h9)
+        # record = constant block + forward stream + 256 padded rows of planes (two inputs, h0..h7, fc_8[1:], ReLU bit planes, h9)
         r32 = lambda v: (v + 31) // 32 * 32
         planes = 256 * 4 * (r32(e_p) + r32(e_d) + 9 * r32(feat) + r32(feat // 2))
         assert lib.nerf_mlp_layered_record_bytes(n, 10) > planes
