@@ -20,9 +20,8 @@
 //  * dW = the dW GEMM kernel of mlp_backward.hip over the same planes (nerf::run_dw_items), thin rows by a vector kernel
 // Padded widths (multiples of 32) carry exact zeros, so they add nothing to any sum.
 //
-// The pass programs are pure functions of the widths (fwd_pass / dx_pass, __host__ __device__): the reverse chain
-// evaluates them on the scalar unit at every pass boundary, the forward tabulates its program in LDS once per launch,
-// the pack kernel evaluates them per slot.
+// The pass programs are pure functions of the widths (fwd_pass / dx_pass, __host__ __device__): the persistent kernels
+// tabulate theirs in LDS once per launch, the pack kernel evaluates them per slot.
 #include <type_traits>
 #include <vector>
 
@@ -640,9 +639,9 @@ __global__ __launch_bounds__(256, 1) void layered_kernel(const WideArgs a) {
     pipe.n_pairs = a.n_pairs; pipe.skip_mask = 0;
     // the pass program, tabulated behind the ring: thread p evaluates pass p once
     int *ptab = reinterpret_cast<int *>(lds + RING_SLOTS * CHUNK_BYTES);
-    // (the forward only: A/B on one box, the reverse chain came out 1-2.5 % SLOWER with the table although its pass
-    // boundaries shrank by 1 k cycles in the timeline -- its scalar program overlaps the mask loads' latency)
-    const bool tabulated = !DX && a.n_passes <= PASS_TABLE_MAX;
+    // (both programs.  While the reverse chain still fetched float masks -- 32 loads in front of a pass's last pair -- it
+    // came out 1-2.5 % slower with the table: its scalar program had overlapped their latency.  With bit planes: +0.5 %)
+    const bool tabulated = a.n_passes <= PASS_TABLE_MAX;
     if (tabulated && tid < a.n_passes) {
         const Pass P = DX ? dx_pass(a.D, a.inputs, tid) : fwd_pass(a.D, tid);
         int k = 0;
