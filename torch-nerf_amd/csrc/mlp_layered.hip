@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
         int64_t m[NSB];
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) m[sb] = row0 + 32 * sb + i;
-        f32x16 pe[NSB][PB], de[NSB];
+        f32x16 pe[NSB][PB];
         auto load_pe = [&]() {
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb)
@@ -842,8 +842,6 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
                 for (int b = 0; b < PB; ++b) pe[sb][b] = load_block(plane(D.r_pe()) + (row0 + 32 * sb) * D.Pp, b, i, h);
         };
         load_pe();
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) de[sb] = load_block(plane(D.r_de()) + (row0 + 32 * sb) * 32, 0, i, h);
         f32x16 acc[NSB][NFB], act[NSB][NFB];
 
         // ---- fc_in (nerf.py:102)
@@ -865,9 +863,10 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
                 for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) act[sb][fb][r] = relu1(acc[sb][fb][r]);
-            // (the stores stay at the seam here: spread over the MFMA groups like the fused family's (PlaneStore) they need a
-            // four-register copy each while accumulators, activations and encodings are all live -- 25..250 B of scratch in
-            // every record variant and 3-5 % slower; at the seam the dead accumulators lend the registers)
+            // (the stores stay at the seam here.  Spread over the MFMA groups like the fused family's (PlaneStore), the
+            // one-sample-block variants spill 160..250 B -- every asm store needs a four-register copy of its data while
+            // accumulators, activations and encodings are all live -- and the two-sample-block variants, which do not spill
+            // once the direction block is fetched late, gain nothing: A/B 2.13 vs 2.10 ms for feat 128.)
             if (RECORD) {
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) {
@@ -907,6 +906,9 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) save_plane<NFB, true>(plane(D.r_h(8)), FP, m[sb], h, act[sb]);
             }
+            f32x16 de[NSB];       // (fetched here, L2-hot, instead of living in 16 NSB registers through fc_in .. fc_8)
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) de[sb] = load_block(plane(D.r_de()) + (row0 + 32 * sb) * 32, 0, i, h);
 #pragma unroll
             for (int fb = 0; fb < HB; ++fb)
 #pragma unroll
