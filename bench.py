@@ -192,13 +192,18 @@ def bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank, steps, warmup):
         for s in range(warmup):
             run(s, s)
         torch.cuda.synchronize()
-        ops.KERNEL_EVENTS = []
-        t0 = time.perf_counter()
-        for s in range(warmup, warmup + steps):
-            render_step(renderer, scene_c, scene_f, pix[s % len(pix)], local_rank)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+        # three rounds of `steps` steps, the median round reported: a 1 ms step is 12 launches, and one descheduling of
+        # the host thread (CFS throttling on a shared box, seen once: 1.98 ms) would otherwise be the figure
+        rounds = []
+        for rnd in range(3):
+            ops.KERNEL_EVENTS = []
+            t0 = time.perf_counter()
+            for s in range(warmup, warmup + steps):
+                render_step(renderer, scene_c, scene_f, pix[s % len(pix)], local_rank)
+            torch.cuda.synchronize()
+            rounds.append((time.perf_counter() - t0, ops.KERNEL_EVENTS))
+        ops.KERNEL_EVENTS = None
+        dt, events = sorted(rounds, key=lambda r: r[0])[1]
         for net in nets:
             net.bf16_inference = False
     durs = [(M, e0.elapsed_time(e1)) for tag, M, e0, e1 in events if tag == "mlp_forward_bf16"]
@@ -211,6 +216,7 @@ def bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank, steps, warmup):
                 "ms_per_launch": round(total_ms / len(durs), 4),
                 "fine_ms_per_launch": round(float(np.mean(fine)), 4) if fine else None}
     return {"rays_per_s": RAYS * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "ms_per_step_rounds": [round(r[0] / steps * 1e3, 4) for r in rounds],
             "psnr_vs_fp32_db": round(10.0 * np.log10(1.0 / mse), 2) if mse > 0 else None,
             "max_abs_err_vs_fp32": (got - ref).abs().max().item(), "roofline": roofline,
             "what": "render step with bf16 weights + bf16 layer inputs (v_mfma_f32_32x32x16_bf16, fp32 accumulate)"}
