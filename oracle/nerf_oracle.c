@@ -512,6 +512,44 @@ ORC_API void orc_mlp_forward(const float *params, int E_p, int E_d, int F, const
     }
 }
 
+/* The values the ten ReLUs of nerf.py:102-118 are applied to, in the mask layout of orc_mlp_backward_ex:
+ * pre (M, 8 F + F/2 + 1) = [fc_in .. fc_7 outputs | fc_9 output | fc_8 output[0]].  Tests use it on a handful of
+ * samples to find the units whose pre-activation sits within rounding of zero -- the only decisions another fp32
+ * summation order (the reference's sgemm, the MFMA chain) can take differently. */
+ORC_API void orc_mlp_preacts(const float *params, int E_p, int E_d, int F, const float *pos_enc,
+                             const float *dir_enc, int64_t M, float *pre)
+{
+    layer_t L[NL];
+    nerf_layout(E_p, E_d, F, L, NULL);
+    const int64_t row_len = 8 * (int64_t)F + F / 2 + 1;
+    float *h = (float *)malloc(sizeof(float) * F);
+    float *y8 = (float *)malloc(sizeof(float) * (F + 1));
+    float *cat5 = (float *)malloc(sizeof(float) * (F + E_p));
+    float *cat9 = (float *)malloc(sizeof(float) * (F + E_d));
+    for (int64_t m = 0; m < M; ++m) {
+        float *row = pre + m * row_len;
+        const float *pe = pos_enc + m * E_p, *de = dir_enc + m * E_d;
+        for (int l = 0; l <= 7; ++l) {
+            if (l == 0) {
+                linear_fwd(params + L[0].w_off, params + L[0].b_off, E_p, F, pe, row);
+            } else if (l == 5) {
+                memcpy(cat5, pe, sizeof(float) * E_p);
+                memcpy(cat5 + E_p, h, sizeof(float) * F);
+                linear_fwd(params + L[5].w_off, params + L[5].b_off, F + E_p, F, cat5, row + 5 * (int64_t)F);
+            } else {
+                linear_fwd(params + L[l].w_off, params + L[l].b_off, F, F, h, row + l * (int64_t)F);
+            }
+            for (int k = 0; k < F; ++k) { const float v = row[l * (int64_t)F + k]; h[k] = v > 0.0f ? v : 0.0f; }
+        }
+        linear_fwd(params + L[8].w_off, params + L[8].b_off, F, F + 1, h, y8);
+        row[8 * (int64_t)F + F / 2] = y8[0];
+        memcpy(cat9, y8 + 1, sizeof(float) * F);
+        memcpy(cat9 + F, de, sizeof(float) * E_d);
+        linear_fwd(params + L[9].w_off, params + L[9].b_off, F + E_d, F / 2, cat9, row + 8 * (int64_t)F);
+    }
+    free(h); free(y8); free(cat5); free(cat9);
+}
+
 /* ------------------------------------------------------------------ */
 /* a13 (MLP part): parameter gradients for upstream (g_sigma (M,),     */
 /* g_rgb (M,3)).  Hand-derived reverse of nerf.py:102-119.  Sums over   */

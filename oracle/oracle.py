@@ -206,6 +206,18 @@ def mlp_backward_ex(params, pos_enc, dir_enc, g_sigma, g_rgb, F=256, want_inputs
     return g, g_pos, g_dir, masks
 
 
+def mlp_preacts(params, pos_enc, dir_enc, F=256):
+    """Pre-activations of the ten ReLUs of nerf.py:102-118 in the mask layout of mlp_backward_ex:
+    (M, 8 F + F/2 + 1) = [fc_in .. fc_7 | fc_9 | fc_8[0]].  Sequential; meant for a handful of samples."""
+    params, pos_enc, dir_enc = _f32(params), _f32(pos_enc), _f32(dir_enc)
+    M, E_p = pos_enc.shape
+    E_d = dir_enc.shape[1]
+    pre = np.zeros((M, 8 * F + F // 2 + 1), np.float32)
+    lib().orc_mlp_preacts(_pf(params), ctypes.c_int(E_p), ctypes.c_int(E_d), ctypes.c_int(F), _pf(pos_enc), _pf(dir_enc),
+                          ctypes.c_int64(M), _pf(pre))
+    return pre
+
+
 def composite_forward(sigma, radiance, delta):
     """R/renderer/integrators/quadrature_integrator.py:14-67."""
     sigma, radiance, delta = _f32(sigma), _f32(radiance), _f32(delta)

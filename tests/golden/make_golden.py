@@ -239,6 +239,15 @@ class ReluSigns:
         bits = np.concatenate(planes, axis=1).astype(np.uint8)
         return np.packbits(bits.reshape(-1)), np.array(bits.shape, np.int64)
 
+    def row_hashes(self):
+        """One 64-bit digest per sample of its 8 F + F/2 + 1 decisions (blake2b over the row's packed bits): what a
+        fixture with 18 432 samples keeps instead of 5 MB of bits.  Equal digests <=> the sample's decisions agree."""
+        import hashlib
+        bits, shape = self.packed()
+        rows = np.packbits(np.unpackbits(bits)[:shape[0] * shape[1]].reshape(tuple(shape)), axis=1)
+        return np.array([int.from_bytes(hashlib.blake2b(r.tobytes(), digest_size=8).digest(), "little") for r in rows],
+                        np.uint64)
+
 
 # ---------------------------------------------------------------- F5 MLP
 def f5_mlp():
@@ -315,6 +324,7 @@ def f7_e2e():
     u1c = torch.rand((n, 64)); u1 = torch.rand((n, 64)); u2 = torch.rand((n, 128)); u3 = torch.rand((n, 128))
     torch.manual_seed(2024)
     pix_t = torch.from_numpy(pix)
+    signs_c, signs_f = ReluSigns(net_c), ReluSigns(net_f)      # one query_points call per pass: ten ReLU calls per network
     c_rgb, c_idx, c_w = vr.render_scene(scene_c, n, 64, False, "cpu", pixel_indices=pix_t)
     c_w_before = c_w.detach().clone()
     f_rgb, f_idx, f_w = vr.render_scene(scene_f, n, (64, 128), False, "cpu", pixel_indices=c_idx,
@@ -328,7 +338,8 @@ def f7_e2e():
                     coarse_w_after=c_w.detach().numpy(), fine_rgb=f_rgb.detach().numpy(),
                     fine_w=f_w.detach().numpy(), loss=np.array([loss.item()]),
                     idx_match=np.array([int(torch.equal(c_idx, pix_t) and torch.equal(f_idx, pix_t))])))
-    for tag, net in (("coarse", net_c), ("fine", net_f)):
+    for tag, net, signs in (("coarse", net_c, signs_c), ("fine", net_f, signs_f)):
+        out[tag + "_relu_hash"] = signs.row_hashes()
         for k, v in grad_digest(net).items():
             out[tag + "_grad_" + k] = v
     save("f7_e2e", **out)
@@ -572,9 +583,116 @@ def f13_instant_ngp():
     print(f"wrote {path}: {rec}")
 
 
+# ---------------------------------------------------------------- F14 the training loop, 20 iterations
+F14 = dict(n=96, steps=20, init_lr=0.0005, end_lr=0.00005, num_iter=40, eps=1e-8, keep=(0, 9, 19))
+
+
+def f14_inputs(step, n=96):
+    """Everything iteration `step` consumes, as pure functions of the step (shared with tests/test_gpu_trajectory.py
+    through this module's twin in tests/helpers.py): camera pose, pixel batch, ground-truth colours and the four
+    uniform tensors the two passes draw, in the order they draw them (coarse: U1c; fine: U1, U2, U3)."""
+    pose = synth.pose_spherical(-180.0 + 18.0 * step, -30.0, 4.0)
+    pix = synth.pixel_batch(140 + step, 800, 800, n)
+    gt = synth.counter_uniform(78, step, n * 3).reshape(n, 3)
+    draws = [synth.counter_uniform(500 + step, k, n * s).reshape(n, s) for k, s in enumerate((64, 64, 128, 128))]
+    return pose, pix, gt, draws
+
+
+class _ReplayDraws:
+    """Stands in for torch.rand / torch.rand_like while the reference runs one iteration: hands out the prepared
+    uniforms in call order and insists on the shapes (stratified_sampler.py:77,109; ray_samplers/utils.py:43,56)."""
+
+    def __init__(self, draws):
+        self.draws = [torch.from_numpy(d.copy()) for d in draws]
+
+    def rand(self, *size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        d = self.draws.pop(0)
+        assert tuple(d.shape) == shape, (d.shape, shape)
+        return d
+
+    def rand_like(self, t, **kw):
+        return self.rand(tuple(t.shape))
+
+
+def param_digest(prefix, now, start):
+    """Digest of a parameter vector and of the update it received (now - start, the part 20 Adam steps wrote)."""
+    d = {}
+    for tag, v in (("p", now), ("dp", now - start)):
+        d[f"{prefix}_{tag}.norm"] = np.array([np.sqrt(np.sum(v.astype(np.float64) ** 2))])
+        d[f"{prefix}_{tag}.head"] = v[:GRAD_SLICE].copy()
+        d[f"{prefix}_{tag}.stride"] = v[:: v.size // (8 * GRAD_SLICE)][: 8 * GRAD_SLICE].copy()
+    return d
+
+
+def f14_train_loop():
+    """The body of runners/train.py:120-218, statement for statement, for 20 consecutive iterations on the reference's
+    classes: new camera, coarse render_scene, MSE, fine render_scene on the coarse pass's (floored in place) weights,
+    MSE, backward, Adam.step, ExponentialLR.step -- optimizer and scheduler built as runner_utils.py:691-711 builds
+    them (num_iter shortened to 40 so that the decay shows within 20 steps).  What only shows ACROSS steps -- the
+    optimizer's moments and step counts, parameters that changed under a cached weight image, the learning-rate
+    schedule, the in-place weight floor feeding the next call -- is pinned by the per-step losses, the pixels of three
+    iterations and digests of both networks' parameters after the last one."""
+    cfg = F14
+    n, steps = cfg["n"], cfg["steps"]
+    flat_c = synth.nerf_flat_params(seed=3, sigma_bias=1.0, sigma_gain=30.0)
+    flat_f = synth.nerf_flat_params(seed=4, sigma_bias=1.0, sigma_gain=30.0)
+    enc = {"coord_enc": RefPE(3, 10, True), "dir_enc": RefPE(3, 4, True)}
+    net_c, net_f = load_ref_net(flat_c), load_ref_net(flat_f)
+    default_scene, fine_scene = ref_scene.PrimitiveCube(net_c, enc), ref_scene.PrimitiveCube(net_f, enc)
+    sampler = ref_samplers.StratifiedSampler()
+    renderer = ref_vr.VolumeRenderer(ref_integrators.QuadratureIntegrator(), sampler,
+                                     camera(800, 800, float(synth.blender_focal(800)), f14_inputs(0)[0], 2.0, 6.0))
+    params = list(default_scene.radiance_field.parameters()) + list(fine_scene.radiance_field.parameters())
+    optimizer = torch.optim.Adam(params, lr=cfg["init_lr"], eps=cfg["eps"])
+    scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, pow(cfg["end_lr"] / cfg["init_lr"], 1 / cfg["num_iter"]))
+    loss_func = torch.nn.MSELoss()
+    rec = dict(coarse_loss=[], fine_loss=[], loss=[], lr=[])
+    out = {}
+    real_rand, real_rand_like = torch.rand, torch.rand_like
+    for step in range(steps):
+        pose, pix, gt, draws = f14_inputs(step, n)
+        pixel_gt = torch.from_numpy(gt)
+        replay = _ReplayDraws(draws)
+        torch.rand, torch.rand_like = replay.rand, replay.rand_like
+        try:
+            loss = 0.0
+            optimizer.zero_grad()
+            renderer.camera = camera(800, 800, float(synth.blender_focal(800)), pose, 2.0, 6.0)
+            coarse_pred, coarse_indices, coarse_weights = renderer.render_scene(
+                default_scene, num_pixels=n, num_samples=64, project_to_ndc=False,
+                pixel_indices=torch.from_numpy(pix), device="cpu")
+            coarse_loss = loss_func(pixel_gt, coarse_pred)
+            loss += coarse_loss
+            fine_pred, fine_indices, _ = renderer.render_scene(
+                fine_scene, num_pixels=n, num_samples=(64, 128), project_to_ndc=False,
+                pixel_indices=coarse_indices, weights=coarse_weights, device="cpu")
+            fine_loss = loss_func(pixel_gt, fine_pred)
+            loss += fine_loss
+        finally:
+            torch.rand, torch.rand_like = real_rand, real_rand_like
+        assert not replay.draws, "the reference consumed fewer uniform tensors than prepared"
+        rec["coarse_loss"].append(coarse_loss.item()); rec["fine_loss"].append(fine_loss.item())
+        rec["loss"].append(loss.item()); rec["lr"].append(optimizer.param_groups[0]["lr"])
+        loss.backward()
+        optimizer.step()
+        scheduler.step()
+        if step in cfg["keep"]:
+            out[f"s{step}_coarse_rgb"] = coarse_pred.detach().numpy()
+            out[f"s{step}_fine_rgb"] = fine_pred.detach().numpy()
+    for k, v in rec.items():
+        out[k] = np.array(v, np.float64)
+    for tag, net, flat in (("coarse", net_c, flat_c), ("fine", net_f, flat_f)):
+        now = np.concatenate([p.detach().numpy().reshape(-1) for p in net.parameters()])
+        out.update(param_digest(tag, now, flat))
+    out["config"] = np.array([n, steps, cfg["init_lr"], cfg["end_lr"], cfg["num_iter"], cfg["eps"]], np.float64)
+    out["keep"] = np.array(cfg["keep"], np.int64)
+    save("f14_train_loop", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    every = dict(f13=f13_instant_ngp, f12=f12_sh_encoder, f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
+    every = dict(f14=f14_train_loop, f13=f13_instant_ngp, f12=f12_sh_encoder, f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
                  f8=f8_adam)
     for name in (sys.argv[1:] or list(every)):      # e.g. `make_golden.py f8` rewrites one fixture
         every[name]()

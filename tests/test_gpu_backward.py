@@ -12,7 +12,8 @@ import torch_nerf.src.renderer.ray_samplers as ray_samplers
 from torch_nerf.src.renderer.volume_renderer import VolumeRenderer
 from torch_nerf.src.signal_encoder import PositionalEncoder
 from torch_nerf.amd import ops, synth
-from helpers import check_grad_digest
+from helpers import (F7_TIGHT, assert_grads_match_given_masks, check_grad_digest, f7_oracle_chain, f7_oracle_grad,
+                     fused_masks, reference_relu_decisions)
 
 pytestmark = pytest.mark.gpu
 
@@ -176,9 +177,25 @@ class _Replay:
         return d
 
 
-def test_training_step_gradients_match_reference(golden, monkeypatch):
+def test_training_step_gradients_match_reference(golden, oracle, monkeypatch):
     """loss = MSE(coarse) + MSE(fine), backward through integrator + MLP of both networks,
-    exactly as runners/train.py:172-215; compared with the reference's gradients (fixture F7)."""
+    exactly as runners/train.py:172-215; compared with the reference's gradients (fixture F7).
+
+    F7 holds a digest per sample of the ReLU decisions the reference's autograd differentiated through.  At 53 M
+    decisions no fp32 evaluation reproduces all of them (~4e-7 sit within rounding of zero: the kernels differ from the
+    reference in ~20 samples, and so do the oracle's plain loops), and one toggled decision moves a gradient row by
+    ~1e-3 of its rms -- which is why this check used to need rtol 5e-4 / atol 2e-2 rms.  Now the decisions are accounted
+    for exactly:
+      1. the reference's decisions are rebuilt from the digests (helpers.reference_relu_decisions) and the kernels' are
+         decoded from the records the two training forwards wrote: they must differ in < 1e-5 of the units;
+      2. the chain is cut where autograd hands the integrator's gradients to the MLP backward (the arguments of
+         ops.mlp_backward, captured): (a) those upstream gradients vs the oracle's double-precision reverse of the
+         quadrature rule on the kernels' own sigma / radiance (rtol 1e-5 + 2e-6 of the ray's largest, as for F6);
+         (b) the parameter gradients vs the oracle differentiating with the KERNELS' decisions and the same upstream:
+         every element of every tensor at rtol 2e-5 + 2e-5 rms;
+      3. the parameter gradients, corrected by what the oracle attributes to the differing decisions (oracle with the
+         reference's decisions minus oracle with the kernels'), vs the reference's digests at F7_TIGHT: rtol 2e-5,
+         6e-4 rms, norms 1e-5 -- the reference's own sgemm summation noise (tests/test_oracle_golden.py measures it)."""
     g = golden("f7_e2e")
     H, W, focal, near, far = g["meta"]
     cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
@@ -191,6 +208,24 @@ def test_training_step_gradients_match_reference(golden, monkeypatch):
     gt = dev(g["gt"])
     dev_i = torch.cuda.current_device()
     monkeypatch.setattr(torch, "rand", _Replay([g["u1c"], g["u1"], g["u2"], g["u3"]]))
+    records = []                                     # (record, sigma, M) of each training forward, in call order
+    real_forward = ops.mlp_forward
+
+    def recording_forward(packed, pos, view_dir, encoded, save=False, net=None):
+        out = real_forward(packed, pos, view_dir, encoded, save=save, net=net)
+        if save:
+            records.append((out[2], out[0], pos.shape[0]))
+        return out
+
+    monkeypatch.setattr(ops, "mlp_forward", recording_forward)
+    upstream = []                                    # (g_sigma, g_rgb) of each MLP backward, in call order (fine first)
+    real_backward = ops.mlp_backward
+
+    def recording_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved, g_sigma, g_rgb, **kw):
+        upstream.append((sigma, rgb, g_sigma, g_rgb))
+        return real_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved, g_sigma, g_rgb, **kw)
+
+    monkeypatch.setattr(ops, "mlp_backward", recording_backward)
     c_rgb, c_idx, c_w = vr.render_scene(scene.PrimitiveCube(net_c, enc), len(pix), 64, False, dev_i,
                                         pixel_indices=pix)
     # fine bins from the reference's coarse weights (sampling carries no gradient)
@@ -200,5 +235,37 @@ def test_training_step_gradients_match_reference(golden, monkeypatch):
     loss = mse(gt, c_rgb) + mse(gt, f_rgb)
     assert abs(loss.item() - float(g["loss"][0])) < 1e-6
     loss.backward()
-    check_grad_digest(flat_grad(net_c), g, "coarse_grad_", rtol=5e-4, atol_scale=2e-2, norm_rtol=5e-4)
-    check_grad_digest(flat_grad(net_f), g, "fine_grad_", rtol=5e-4, atol_scale=2e-2, norm_rtol=5e-4)
+    assert [r[2] for r in records] == [96 * 64, 96 * 192]
+    assert [u[0].shape[0] for u in upstream] == [96 * 192, 96 * 64]
+    chain = f7_oracle_chain(oracle, g)
+    for (saved, sigma, M), up, pixels, tag, net in zip(records, upstream[::-1], (c_rgb, f_rgb), ("coarse", "fine"),
+                                                       (net_c, net_f)):
+        c = chain[tag]
+        n, S = c["delta"].shape
+        k_sigma, k_rgb, k_gs, k_gc = (t.detach().cpu().numpy() for t in up)
+        # 2a: the integrator's reverse pass on the kernels' own forward values
+        g_pixels = (2.0 * (pixels.detach().cpu().numpy() - g["gt"]) / np.float32(n * 3)).astype(np.float32)
+        want_s, want_c = oracle.composite_backward(k_sigma.reshape(n, S), k_rgb.reshape(n, S, 3), c["delta"], g_pixels)
+        err = np.abs(k_gs.reshape(n, S) - want_s)
+        # F6's bound (test_gpu_kernels.py: rtol 1e-5 + 2e-6 of the ray's largest + an absolute floor), the floor scaled
+        # to THIS loss's pixel gradients: d sigma_i = delta_i (T_{i+1} G_i - sum_{k>i} w_k G_k) cancels two terms of size
+        # delta |g| whose fp32 exp() carry 6e-8 each -- on rays where they cancel completely (row maximum ~ 0) that
+        # leaves ~1e-8 |g| (measured worst: 1.07e-8 |g|); 3e-8 |g| allowed
+        bound = 1e-5 * np.abs(want_s) + 2e-6 * np.abs(want_s).max(axis=1, keepdims=True) + 3e-8 * np.abs(g_pixels).max()
+        assert np.all(err <= bound), (tag, float((err / bound).max()))
+        np.testing.assert_allclose(k_gc.reshape(n, S, 3), want_c, rtol=1e-5, atol=1e-7 * np.abs(g_pixels).max())
+        # 1: decisions
+        ref_masks, _, unresolved = reference_relu_decisions(oracle, c["params"], c["pe"], c["de"], c["masks"],
+                                                            g[tag + "_relu_hash"])
+        assert unresolved.size == 0
+        mine = fused_masks(saved, sigma, M)
+        flips = int((mine != ref_masks).sum())
+        assert flips < 1e-5 * ref_masks.size, f"{tag}: {flips} of {ref_masks.size} ReLU decisions differ from the reference's"
+        # 2b: the MLP's reverse pass, same decisions and same upstream on both sides
+        ck = dict(c, g_sigma=k_gs.reshape(-1), g_rgb=k_gc.reshape(-1, 3))
+        got = flat_grad(net)
+        with_mine = f7_oracle_grad(oracle, ck, mine)
+        assert_grads_match_given_masks(got, with_mine, synth.split_flat_params, tag=f"{tag} ({flips} flips): ")
+        # 3: against the reference's numbers
+        corrected = got + (f7_oracle_grad(oracle, ck, ref_masks) - with_mine) if flips else got
+        check_grad_digest(corrected, g, tag + "_grad_", **F7_TIGHT)

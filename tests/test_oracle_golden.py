@@ -178,6 +178,25 @@ def test_end_to_end(golden, oracle):
     np.testing.assert_allclose(f["weights"], g["fine_w"], rtol=0, atol=1e-5)
 
 
+def test_end_to_end_gradients_with_the_references_relu_decisions(golden, oracle):
+    """loss = MSE(coarse) + MSE(fine) differentiated through integrator + MLP of both networks (train.py:172-215)
+    against the gradients the reference's autograd returned (F7 digests).  F7 keeps a 64-bit digest per sample of the
+    ReLU decisions autograd differentiated through; the oracle's own differ from them in ~20 of 24 576 samples
+    (one unit each, pre-activation within rounding of zero).  They are rebuilt exactly (helpers.
+    reference_relu_decisions: toggle marginal units until the digest matches), forced into the oracle's backward, and
+    the result is compared at summation-order tolerance -- 30x tighter than a flip-blind comparison allows."""
+    from helpers import F7_TIGHT, check_grad_digest, f7_oracle_chain, f7_oracle_grad, reference_relu_decisions
+    g = golden("f7_e2e")
+    chain = f7_oracle_chain(oracle, g)
+    for tag, c in chain.items():
+        ref_masks, differing, unresolved = reference_relu_decisions(oracle, c["params"], c["pe"], c["de"], c["masks"],
+                                                                    g[tag + "_relu_hash"])
+        assert unresolved.size == 0, f"{tag}: decisions of samples {unresolved} could not be rebuilt"
+        toggled = int((ref_masks != c["masks"]).sum())
+        assert toggled < 1e-5 * ref_masks.size, (tag, toggled)          # measured: 5 / 15 units of 13.4 M / 40.1 M
+        check_grad_digest(f7_oracle_grad(oracle, c, ref_masks), g, tag + "_grad_", **F7_TIGHT)
+
+
 def test_adam_and_exponential_lr(golden, oracle):
     """Row f1: the optimizer step (runner_utils.py:691-711, train.py:215-218) against torch.optim.Adam +
     ExponentialLR driven the reference's way.  The learning-rate sequence is exact (double arithmetic);
