@@ -32,6 +32,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -281,8 +282,17 @@ def cpu_baseline(flats, focal, pose, device):
 
 
 def hbm_stages(device, reps=20):
+    """The HBM-bound stages at the training batch (4096 rays: latency-bound, a lower bound on the streaming rate) and at
+    frame scale (65 536 and 640 000 rays = a whole 800x800 frame in one launch: the streaming rate itself)."""
+    out = hbm_stages_at(device, RAYS, reps)
+    for n in (65536, H * W):
+        out[f"rays_{n}"] = hbm_stages_at(device, n, max(5, reps // 2))
+    return out
+
+
+def hbm_stages_at(device, n_rays, reps=20):
     """the stages outside the MLP are HBM-bound and reported separately against 8 TB/s.
-    Each kernel at the full batch (4096 rays; 64 or 64+128 samples) straight through the C ABI on preallocated
+    Each kernel at `n_rays` rays (64 or 64+128 samples) straight through the C ABI on preallocated
     buffers: `reps` launches back to back behind a GPU-side sleep (so that the host is ahead and the events see
     kernel time + launch boundary only), HIP events around the run; bytes = the algorithmic traffic of the
     stage.  (Inference runs these stages inside the fused render kernel; training runs them
@@ -290,7 +300,7 @@ def hbm_stages(device, reps=20):
     import ctypes
     from torch_nerf.amd import _lib
     lib = _lib.load()
-    n, Sc, Sf = RAYS, N_COARSE, N_FINE
+    n, Sc, Sf = n_rays, N_COARSE, N_FINE
     S = Sc + Sf
     g = torch.Generator(device=device).manual_seed(5)
     o = torch.randn((n, 3), device=device, generator=g)
@@ -342,8 +352,9 @@ def hbm_stages(device, reps=20):
         out[name] = {"us": round(t * 1e3, 2), "bytes": nbytes, "achieved_GBs": round(gbs, 1),
                      "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "traffic": what}
     out["note"] = (f"{n} rays x {Sc} (stratified) / {Sc}+{Sf} (others) samples, mean of {reps} back-to-back launches "
-                   "(kernel + launch boundary); one-wave-per-ray kernels of 5-45 us are latency-bound at this batch "
-                   "size, so the fraction is a lower bound on their streaming rate")
+                   "(kernel + launch boundary)" + ("; one-wave-per-ray kernels of 5-45 us are latency-bound at this batch "
+                   "size, so the fraction is a lower bound on their streaming rate (rays_65536 / rays_640000 hold the "
+                   "frame-scale figures)" if n <= 4096 else ""))
     return out
 
 
@@ -367,14 +378,20 @@ def frame_leg(nets, cam, rank, world, device, dist_on=None):
         torch.cuda.synchronize()
     shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1)      # warm-up (collective included)
     fence()
+    stats = {}
     t0 = time.perf_counter()
-    img = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1)
+    img = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, False, seed=1, stats=stats)
     fence()
     dt = time.perf_counter() - t0
+    mine = [stats["render_events"][0].elapsed_time(stats["render_events"][1]), float(stats["launches"]), float(stats["rays"])]
+    per_rank = [mine]
     if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        every = torch.empty((world, 3), device=device, dtype=torch.float64)      # each rank's own rendering, gather excluded
+        dist.all_gather_into_tensor(every, torch.tensor([mine], device=device, dtype=torch.float64))
+        per_rank = every.tolist()
     digest = hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()[:16]
     gather_ms = None
     if dist_on:    # the frame's ONE collective on its own: the same (H*W/world, 3) slabs, rendering excluded
@@ -393,6 +410,8 @@ def frame_leg(nets, cam, rank, world, device, dist_on=None):
         gather_ms = t.item() * 1e3
     out = {"ms": dt * 1e3, "rays_per_s": H * W / dt, "rays": H * W, "n_gpus": world, "scaling": "strong",
            "gather_ms": gather_ms,
+           "ms_per_rank": [round(r[0], 3) for r in per_rank],       # GPU time of each rank's own launches (no collective)
+           "launches_per_rank": [int(r[1]) for r in per_rank], "rays_per_rank": [int(r[2]) for r in per_rank],
            "image_sha256_16": digest,
            "what": f"{W}x{H} frame, 64+128 samples, fp32, contiguous pixel ranges over {world} rank(s), "
                    "all-gather of the (H*W/world, 3) slabs included"}
@@ -687,6 +706,60 @@ def configs_leg(nets, flats, device):
     return out
 
 
+def encoder_variants_leg(device, local_rank, steps, warmup):
+    """Whole-pass rays/s -- sampling + encoder kernel + network kernel + integral, coarse then fine, through
+    VolumeRenderer.render_scene exactly like the headline step -- for the encoder settings the reference's yaml can
+    name beyond the shipped 10 / 4 (configs/signal_encoder/positional_encoding.yaml:2-3, sh.yaml; runner_utils.py:584-612
+    builds NeRF(coord_enc.out_dim, dir_enc.out_dim) behind them).  None of them fits the single-kernel render pass
+    (pos_dim > 64, view_dir_dim > 32 or not a PositionalEncoder): each pass is the kernel chain.  `mlp_frac` = the
+    algorithmic MLP FLOPs of the step (UNPADDED widths) over the whole step time, of the fp32 MFMA peak; `frame` = the
+    800x800 frame through shard.render_frame's chain fallback."""
+    import torch_nerf.src.network as network
+    import torch_nerf.src.scene as scene
+    from torch_nerf.src.signal_encoder import PositionalEncoder, SHEncoder
+    from torch_nerf.amd import shard, synth
+    renderer = build_scene(device)[0]
+    cam = renderer.camera
+    pix = [((torch.arange(RAYS, device=device) + s * RAYS) % (H * W)) for s in range(warmup + steps)]
+    variants = {"coord_l12": (PositionalEncoder(3, 12, True), PositionalEncoder(3, 4, True)),
+                "dir_l5": (PositionalEncoder(3, 10, True), PositionalEncoder(3, 5, True)),
+                "sh": (SHEncoder(3, 4), SHEncoder(3, 4))}
+    out = {}
+    for tag, (ce, de) in variants.items():
+        scenes = []
+        for seed in (3, 4):
+            flat = synth.nerf_flat_params(seed=seed, pos_dim=ce.out_dim, view_dir_dim=de.out_dim, sigma_bias=1.0, sigma_gain=30.0)
+            net = network.NeRF(ce.out_dim, de.out_dim)
+            net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in
+                                 synth.split_flat_params(flat, ce.out_dim, de.out_dim, 256).items()})
+            scenes.append(scene.PrimitiveCube(net.to(device), {"coord_enc": ce, "dir_enc": de}))
+        torch.manual_seed(99)
+        with torch.no_grad():
+            for s in range(warmup):
+                render_step(renderer, scenes[0], scenes[1], pix[s], local_rank)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s in range(warmup, warmup + steps):
+                _, f_rgb = render_step(renderer, scenes[0], scenes[1], pix[s], local_rank)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            shard.render_frame(cam, scenes[0], scenes[1], N_COARSE, N_FINE, False, seed=1, single_rank=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            img = shard.render_frame(cam, scenes[0], scenes[1], N_COARSE, N_FINE, False, seed=1, single_rank=True)
+            torch.cuda.synchronize()
+            dt_frame = time.perf_counter() - t0
+        flop = 2 * sum(o * i for o, i in synth.layer_shapes(ce.out_dim, de.out_dim, 256)) * RAYS * (2 * N_COARSE + N_FINE)
+        out[tag] = {"network": f"NeRF({ce.out_dim}, {de.out_dim}, 256)", "path": "fused family, pre-encoded entry" if scenes[0].radiance_field._net.fused else "layered family",
+                    "ms_per_step": dt * 1e3, "rays_per_s": RAYS / dt, "mlp_frac": flop / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    "finite": bool(torch.isfinite(f_rgb).all()),
+                    "frame": {"ms": dt_frame * 1e3, "rays_per_s": H * W / dt_frame, "finite": bool(torch.isfinite(img).all())}}
+    out["what"] = ("4096 rays x (64+128), fp32, coarse + fine render_scene per step (the headline step's two calls) behind "
+                   "non-default encoders: kernel chain sampling -> encode -> network -> integral; frame = 800x800 via "
+                   "shard.render_frame(scenes)")
+    return out
+
+
 def traffic_leg():
     """HBM traffic of the step's kernels, measured in THIS run: two child processes re-run a
     short bench (render + bf16 + train legs) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
@@ -753,6 +826,36 @@ def traffic_leg():
             "mlp_bwd_dw_kernel": kernel("mlp_bwd_dw_kernel")}
 
 
+def per_rank_times(elapsed: float, steps: int, world: int, device):
+    """Every rank's ms per step, gathered to all (a bad N-GPU number must be diagnosable from the line alone)."""
+    mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    every = torch.empty((world,), device=device, dtype=torch.float64)
+    dist.all_gather_into_tensor(every, mine)
+    ms = (every / steps * 1e3).tolist()
+    return {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "rank_of_max": int(np.argmax(ms)),
+            "ms_per_step": [round(v, 4) for v in ms]}, float(every.max().item())
+
+
+def nccl_debug_setup(rank: int):
+    """RCCL's own warnings (NCCL_DEBUG=WARN: failed IPC handles, unreachable peers, aborted communicators) go to a file
+    per rank, so that a failing collective can quote them in the JSON line instead of losing them in a launcher log."""
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    if "NCCL_DEBUG_FILE" not in os.environ:
+        os.environ["NCCL_DEBUG_FILE"] = os.path.join(tempfile.gettempdir(), f"nerf_bench_rccl_{os.getpid()}_r{rank}.log")
+    return os.environ["NCCL_DEBUG_FILE"]
+
+
+def nccl_debug_tail(path, limit=1500):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            size = f.tell()
+            f.seek(max(0, size - limit))
+            return f.read().decode("utf-8", "replace").strip() or None
+    except OSError:
+        return None
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process (never exec
     from a process that may have initialised the GPU; this one has not) and hand back its return code."""
@@ -783,7 +886,8 @@ def main():
     ap.add_argument("--no-stages", action="store_true", help="skip the HBM-bound stage measurements")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes that measure HBM "
                     "traffic (roofline.traffic is then null)")
-    ap.add_argument("--no-configs", action="store_true", help="skip the llff (configs[3]) and coarse400 (configs[0]) legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the llff (configs[3]), coarse400 (configs[0]), ship_bf16 (configs[2]) and "
+                    "non-default-encoder legs")
     ap.add_argument("--no-runner-loop", action="store_true", help="skip the runners/train.py-shaped training loop leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the multi-rank path on a box with fewer GPUs than ranks)")
@@ -809,6 +913,7 @@ def main():
 
     if args.launch_check:
         seen = torch.ones(1)
+        per_rank = frame = None
         if world > 1:
             dist.init_process_group("gloo" if args.backend != "nccl" or not torch.cuda.is_available() else "nccl",
                                     timeout=datetime.timedelta(seconds=args.dist_timeout))
@@ -816,9 +921,24 @@ def main():
                 os._exit(17)
             dist.all_reduce(seen)
             dist.barrier()
+            # the collectives of the real run, on stand-in data: the per-step slab gather, the per-rank time gather and
+            # the frame leg's (world, 3) statistics gather -- same shapes of output as the N-GPU line
+            slab, full = torch.zeros((RAYS, 3)), torch.empty((world * RAYS, 3))
+            t0 = time.perf_counter()
+            for _ in range(max(1, args.steps)):
+                dist.all_gather_into_tensor(full, slab)
+            per_rank, _ = per_rank_times(time.perf_counter() - t0, max(1, args.steps), world, torch.device("cpu"))
+            from torch_nerf.amd import shard
+            lo, hi = shard.shard_range(H * W, rank, world)
+            every = torch.empty((world, 3), dtype=torch.float64)
+            dist.all_gather_into_tensor(every, torch.tensor([[0.0, float(-(-(hi - lo) // 131072)), float(hi - lo)]],
+                                                            dtype=torch.float64))
+            frame = {"launches_per_rank": [int(r[1]) for r in every.tolist()],
+                     "rays_per_rank": [int(r[2]) for r in every.tolist()]}
         if rank == 0:
             print(json.dumps({"metric": "rays/sec at 4096 rays x (64+128) samples", "value": None, "unit": "rays/s",
                               "n_gpus": world, "rccl_ranks_seen": int(seen.item()), "launch_check": True,
+                              "per_rank": per_rank, "frame": frame,
                               "steps": args.steps, "warmup": args.warmup}), flush=True)
         if world > 1:
             dist.destroy_process_group()
@@ -838,17 +958,28 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0",
                                   WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
+        # the host driver of this pool supports dmabuf IPC only: with the legacy mode RCCL's (and torch's) cross-process
+        # buffer sharing fails in hipIpcGetMemHandle ("invalid argument").  Exported on the boxes already; kept here
+        # for launches from a bare environment
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         tmo = datetime.timedelta(seconds=args.dist_timeout)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device, timeout=tmo)
-        else:
-            dist.init_process_group(args.backend, timeout=tmo)
-        if rank == args.fault_rank:
-            os._exit(17)
-        seen = torch.ones(1, device=device)
-        dist.all_reduce(seen)                      # every rank really is on the communicator
-        ranks_seen = int(seen.item())
+        nccl_log = nccl_debug_setup(rank) if args.backend == "nccl" else None
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=device, timeout=tmo)
+            else:
+                dist.init_process_group(args.backend, timeout=tmo)
+            if rank == args.fault_rank:
+                os._exit(17)
+            seen = torch.ones(1, device=device)
+            dist.all_reduce(seen)                      # every rank really is on the communicator
+            ranks_seen = int(seen.item())
+        except Exception as exc:  # noqa: BLE001 -- no headline line can follow: leave the evidence on stderr and fail
+            print(json.dumps({"bench_failed": "process group / first collective", "rank": rank, "world": world,
+                              "error": f"{type(exc).__name__}: {exc}"[:500],
+                              "rccl_warnings_tail": nccl_debug_tail(nccl_log) if nccl_log else None}),
+                  file=sys.stderr, flush=True)
+            raise
 
     from torch_nerf.amd import ops
     renderer, scene_c, scene_f, nets, flats, cam, focal, pose = build_scene(device)
@@ -902,13 +1033,7 @@ def main():
     per_step = [a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:])]
     per_rank = None
     if dist_on:
-        mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        every = torch.empty((world,), device=device, dtype=torch.float64)
-        dist.all_gather_into_tensor(every, mine)       # a bad N-GPU number must be diagnosable from the line alone
-        ms = (every / args.steps * 1e3).tolist()
-        per_rank = {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "rank_of_max": int(np.argmax(ms)),
-                    "ms_per_step": [round(v, 4) for v in ms]}
-        elapsed = float(every.max().item())
+        per_rank, elapsed = per_rank_times(elapsed, args.steps, world, device)
 
     # ---- dominant kernel: the fused render pass (sampling + encode + MLP + integral in one kernel), two launches
     # per step: coarse pass M = 4096 x 64 and fine pass M = 4096 x 192 samples.  achieved = algorithmic MLP FLOPs
@@ -970,7 +1095,10 @@ def main():
         try:
             return fn()
         except Exception as exc:  # noqa: BLE001
-            return {"error": f"{type(exc).__name__}: {exc}"[:300], "leg": name}
+            err = {"error": f"{type(exc).__name__}: {exc}"[:300], "leg": name}
+            if dist_on and args.backend == "nccl":     # what RCCL itself said (NCCL_DEBUG=WARN, per-rank file)
+                err["rccl_warnings_tail"] = nccl_debug_tail(os.environ.get("NCCL_DEBUG_FILE", ""))
+            return err
 
     if not args.no_frame:       # collective: every rank takes part
         result["frame"] = guarded("frame", lambda: frame_leg(nets, cam, rank, world, device, dist_on))
@@ -984,6 +1112,8 @@ def main():
                 result["frame_api"]["vs_frame_leg"] = result["frame_api"]["ms"] / result["frame"]["ms"]
     if rank == 0 and world == 1 and not args.no_configs:     # before the train leg: that one UPDATES the networks
         result["configs"] = guarded("configs", lambda: configs_leg(nets, flats, device))
+    if rank == 0 and world == 1 and not args.no_configs:
+        result["encoders"] = guarded("encoders", lambda: encoder_variants_leg(device, local_rank, max(5, args.steps // 4), 2))
     if world == 1 and not args.no_bf16:
         result["bf16"] = guarded("bf16", lambda: bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank,
                                                           args.steps, 3))

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 3
+#define NERF_AMD_ABI_VERSION 4
 
 enum {
     NERF_OK = 0,
@@ -156,9 +156,11 @@ int nerf_mlp_backward(const nerf_net_t *net, const void *packed, const float *pa
  * stream, v_mfma_f32_32x32x2_f32 with the weights as the A operand -- with the activations of a tile parked in HBM
  * planes between layers (a network of feat_dim 512 does not fit the register file); bias, ReLU / sigmoid and the two
  * torch.cat of nerf.py:108,:116 are fused; every call packs its streams from `params` first.
- *   record_rows >= M : the whole batch is recorded (what nerf_mlp_layered_backward needs)
- *   record_rows <  M : inference, the batch is walked in chunks through the same buffer (record_rows rows each; networks
- *                      whose activations stay in registers need only the two input planes and take longer chunks)
+ *   keep_record != 0 : the whole batch is recorded (what nerf_mlp_layered_backward needs); requires record_rows >= M
+ *   keep_record == 0 : inference, the batch is walked in chunks of <= record_rows rows through the same buffer; networks
+ *                      whose activations stay in registers write NO activation planes, need only the two input planes
+ *                      of the buffer and take longer chunks (ABI v4: was inferred from record_rows >= M, which made
+ *                      every inference call of <= 65536 rows a recording one)
  * record = nerf_mlp_layered_record_bytes(net, record_rows) bytes (constant block + forward stream + planes).
  * Backward = autograd's result for nerf.py:102-119: g_params (OVERWRITTEN, layout of `params`) and, when non-NULL,
  * g_pos (M,pos_dim) / g_view_dir (M,view_dir_dim), the gradients w.r.t. the encoded inputs.  No atomics: the
@@ -173,7 +175,7 @@ int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t M);
 int64_t nerf_mlp_layered_plane(const nerf_net_t *net, int64_t rows, int which, int *width);
 int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params, const float *pos, const float *view_dir,
                              int64_t M, float *sigma, float *rgb, void *record, int64_t record_rows,
-                             nerf_stream_t stream);
+                             int keep_record, nerf_stream_t stream);
 int nerf_mlp_layered_backward(const nerf_net_t *net, const float *params, const float *pos, const float *view_dir,
                               int64_t M, const float *sigma, const float *rgb, const void *record,
                               const float *g_sigma, const float *g_rgb, float *g_params, float *g_pos,

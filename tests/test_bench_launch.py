@@ -31,6 +31,16 @@ def test_self_launch_two_ranks_gloo():
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["launch_check"] is True
 
 
+def test_self_launch_eight_ranks_gloo():
+    """The shape of the driver's 8-GPU run, on CPU: eight ranks through the real self-launch, every collective of the
+    N-rank line on stand-in data (slab all-gather per step, per-rank time gather, the frame leg's statistics gather)."""
+    line = _run("--gpus", "8", "--backend", "gloo", "--launch-check", "--steps", "3")
+    assert line["n_gpus"] == 8 and line["rccl_ranks_seen"] == 8
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and pr["ms_per_step_min"] <= pr["ms_per_step_max"] and 0 <= pr["rank_of_max"] < 8
+    assert line["frame"]["rays_per_rank"] == [80000] * 8 and line["frame"]["launches_per_rank"] == [1] * 8
+
+
 def test_single_rank_needs_no_launcher():
     line = _run("--gpus", "1", "--backend", "gloo", "--launch-check")
     assert line["n_gpus"] == 1 and line["rccl_ranks_seen"] == 1
@@ -58,6 +68,19 @@ def test_a_rank_that_dies_before_the_first_collective_ends_the_run():
     assert time.time() - t0 < 120
 
 
+def test_a_dying_rank_among_eight_ends_the_run():
+    """The same failure with the driver's rank count: rank 5 of 8 exits before the first collective."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo",
+                          "--launch-check", "--fault-rank", "5", "--dist-timeout", "20"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], out.stdout[-500:]
+    assert time.time() - t0 < 150
+
+
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_full_bench():
     first, line = _run("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
@@ -65,6 +88,8 @@ def test_two_ranks_on_one_gpu_full_bench():
     pr = line["per_rank"]        # what a bad N-GPU number is diagnosed from
     assert len(pr["ms_per_step"]) == 2 and pr["ms_per_step_min"] <= pr["ms_per_step_max"] and pr["rank_of_max"] in (0, 1)
     assert line["frame"]["gather_ms"] > 0
+    assert len(line["frame"]["ms_per_rank"]) == 2 and min(line["frame"]["ms_per_rank"]) > 0
+    assert line["frame"]["rays_per_rank"] == [320000, 320000] and line["frame"]["launches_per_rank"] == [3, 3]
     assert "error" not in line["train"], line["train"]          # data-parallel leg: on by default since round 4
     # the headline line leaves before any secondary (collective) leg; the last line repeats it and adds the legs
     assert first["partial"] and "frame" not in first and first["value"] == line["value"] and "partial" not in line

@@ -1,0 +1,151 @@
+"""Encoder settings the reference's yaml can name beyond the shipped 10 / 4, END TO END through the class API
+(VERDICT r04 item 4): `coord_encode_level: 12`, `dir_encode_level: 5`
+(configs/signal_encoder/positional_encoding.yaml:2-3 -> runner_utils.py:585-612 builds NeRF(75, 27) / NeRF(63, 33)) and
+`signal_encoder: sh` (configs/signal_encoder/sh.yaml -> NeRF(16, 16), :595-604).  None of them is served by the
+single-kernel render pass (pos_dim > 64, view_dir_dim > 32, or no PositionalEncoder): render_scene runs the kernel
+chain sampling -> encoder kernel -> network kernel -> integral, and so does shard.render_frame.
+
+Checked here, per variant: both passes of VolumeRenderer.render_scene against the oracle on the same rays and draws
+(pixel colours and weights within 1e-5 abs, the north_star bound), in inference and in training mode (the two modes
+take different kernels: no-record vs record forward), the fine pass's in-place weight floor, and that the sharded
+frame does not depend on how it is cut into launches / ranks."""
+import numpy as np
+import pytest
+import torch
+
+import torch_nerf.src.network as network
+import torch_nerf.src.scene as scene
+import torch_nerf.src.renderer.cameras as cameras
+import torch_nerf.src.renderer.integrators.quadrature_integrator as integrators
+import torch_nerf.src.renderer.ray_samplers as ray_samplers
+from torch_nerf.src.renderer.volume_renderer import VolumeRenderer
+from torch_nerf.src.signal_encoder import PositionalEncoder, SHEncoder
+from torch_nerf.amd import ops, shard, synth
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {   # tag: (coord encoder, direction encoder) as runner_utils.py:584-604 builds them
+    "coord_l12": lambda: (PositionalEncoder(3, 12, True), PositionalEncoder(3, 4, True)),
+    "dir_l5": lambda: (PositionalEncoder(3, 10, True), PositionalEncoder(3, 5, True)),
+    "coord_l12_dir_l6": lambda: (PositionalEncoder(3, 12, True), PositionalEncoder(3, 6, True)),
+    "sh": lambda: (SHEncoder(3, 4), SHEncoder(3, 4)),
+}
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def build(tag):
+    ce, de = VARIANTS[tag]()
+    nets, flats = [], []
+    for seed in (3, 4):
+        flat = synth.nerf_flat_params(seed=seed, pos_dim=ce.out_dim, view_dir_dim=de.out_dim, sigma_bias=1.0, sigma_gain=8.0)
+        net = network.NeRF(ce.out_dim, de.out_dim)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in
+                             synth.split_flat_params(flat, ce.out_dim, de.out_dim, 256).items()})
+        nets.append(net.cuda())
+        flats.append(flat)
+    enc = {"coord_enc": ce, "dir_enc": de}
+    return [scene.PrimitiveCube(n, enc) for n in nets], flats, (ce, de)
+
+
+def oracle_encode(oracle, enc, x):
+    if isinstance(enc, SHEncoder):
+        return oracle.shenc(x, enc.degree)
+    return oracle.posenc(x, enc.embed_level, enc.include_input)
+
+
+def oracle_pass(oracle, flat, encs, o, d, t_bins, ps, u1, weights=None, u2=None, u3=None):
+    """-> (pixel colours, weights, the input weights after the sampler's in-place floor | None)"""
+    after = None
+    if weights is None:
+        t, pts, dirs, delta = oracle.stratified_sample(o, d, t_bins, ps, u1)
+    else:
+        _, t, pts, dirs, delta, after = oracle.hierarchical_sample(o, d, t_bins, ps, weights, u1, u2, u3)
+    n, S = delta.shape
+    sigma, rgb = oracle.mlp_forward(flat, oracle_encode(oracle, encs[0], pts.reshape(-1, 3)),
+                                    oracle_encode(oracle, encs[1], dirs.reshape(-1, 3)))
+    return (*oracle.composite_forward(sigma.reshape(n, S), rgb.reshape(n, S, 3), delta), after)
+
+
+class _Replay:
+    def __init__(self, draws):
+        self.draws = [dev(d) for d in draws]
+
+    def __call__(self, shape, device=None, **kw):
+        d = self.draws.pop(0)
+        assert tuple(d.shape) == tuple(shape)
+        return d
+
+
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("tag", sorted(VARIANTS))
+def test_render_scene_matches_oracle(oracle, monkeypatch, tag, training):
+    H = W = 800
+    focal = float(synth.blender_focal(W))
+    pose = synth.pose_spherical(37.0, -30.0, 4.0)
+    n = 96
+    pix = synth.pixel_batch(21, H, W, n)
+    draws = [d.numpy() for d in shard.ray_draws(13, 0, n, 64, 128, "cpu")]
+    scenes, flats, encs = build(tag)
+    assert scenes[0].fused_net() is None                         # not the single-kernel pass: that is the point
+    cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
+                                    torch.from_numpy(pose), 2.0, 6.0)
+    vr = VolumeRenderer(integrators.QuadratureIntegrator(), ray_samplers.StratifiedSampler(), cam)
+    k4 = (np.float32(focal), np.float32(focal), W / 2.0, H / 2.0)
+    o, d = oracle.raygen(oracle.screen_coords(H, W, pix), *k4, pose)
+    t_bins = torch.linspace(2.0, 6.0, 65)[:-1].numpy()
+    ps = 4.0 / 64
+    want_c, want_cw, _ = oracle_pass(oracle, flats[0], encs, o, d, t_bins, ps, draws[0])
+    want_f, want_fw, floored = oracle_pass(oracle, flats[1], encs, o, d, t_bins, ps, draws[1], want_cw, draws[2], draws[3])
+    monkeypatch.setattr(torch, "rand", _Replay(draws))
+    di = torch.cuda.current_device()
+    with torch.set_grad_enabled(training):
+        c_rgb, idx, c_w = vr.render_scene(scenes[0], n, 64, False, di, pixel_indices=torch.from_numpy(pix))
+        assert c_rgb.requires_grad == training
+        np.testing.assert_allclose(c_rgb.detach().cpu().numpy(), want_c, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(c_w.detach().cpu().numpy(), want_cw, rtol=0, atol=1e-5)
+        # the fine pass on the ORACLE's coarse weights, so that the bins are comparable sample for sample
+        w_in = dev(want_cw)
+        f_rgb, _, f_w = vr.render_scene(scenes[1], n, (64, 128), False, di, pixel_indices=idx, weights=w_in)
+    assert np.array_equal(w_in.cpu().numpy(), floored)          # `weights += 1e-5` in place (ray_samplers/utils.py:31)
+    np.testing.assert_allclose(f_rgb.detach().cpu().numpy(), want_f, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(f_w.detach().cpu().numpy(), want_fw, rtol=0, atol=1e-5)
+    if training:          # and the chain is differentiable end to end (gradients themselves: test_gpu_variants / _sh)
+        (c_rgb.sum() + f_rgb.sum()).backward()
+        for sc in scenes:
+            g = torch.cat([p.grad.reshape(-1) for p in sc.radiance_field.parameters()])
+            assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+
+
+@pytest.mark.parametrize("tag", ["coord_l12", "dir_l5", "sh"])
+def test_sharded_frame_through_the_kernel_chain(tag):
+    """shard.render_frame no longer refuses networks outside the fused family: given the scene primitives it runs the
+    chain per launch.  The image must not depend on the launch granularity (hence not on the rank count), must equal a
+    two-way split rendered range by range, and must equal what render_scene returns for the same rays and draws."""
+    H, W = 48, 64
+    focal = 70.0
+    cam = cameras.PerspectiveCamera({"f_x": focal, "f_y": focal, "img_width": W, "img_height": H},
+                                    torch.from_numpy(synth.pose_spherical(10.0, -30.0, 4.0)), 2.0, 6.0)
+    scenes, _, _ = build(tag)
+    a = shard.render_frame(cam, scenes[0], scenes[1], 64, 128, False, seed=5, single_rank=True)
+    b = shard.render_frame(cam, scenes[0], scenes[1], 64, 128, False, seed=5, rays_per_launch=1000)
+    assert a.shape == (H * W, 3) and torch.equal(a, b)
+    assert bool(torch.isfinite(a).all()) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0 + 1e-6 and float(a.std()) > 1e-3
+    with pytest.raises(RuntimeError, match="scene primitives"):
+        shard.render_frame(cam, scenes[0].radiance_field, scenes[1].radiance_field, 64, 128, False, seed=5)
+    parts = []
+    s = ray_samplers.StratifiedSampler()
+    t_bins, ps = s._create_t_bins(2.0, 6.0, 64, "cuda")
+    for r in range(2):
+        lo, hi = shard.shard_range(H * W, r, 2)
+        bundle = s.generate_rays_from_pixels(cam, False, first=lo, count=hi - lo)
+        u1c, u1, u2, u3 = shard.ray_draws(5, lo, hi - lo, 64, 128, "cuda")
+        with torch.no_grad():
+            pts, dirs, delta = ops.sample_stratified(bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c)
+            _, w = ops.composite_forward(*scenes[0].query_points(pts, dirs), delta)
+            pts, dirs, delta = ops.sample_hierarchical(bundle.ray_origin, bundle.ray_dir, t_bins, ps, w, u1, u2, u3)
+            rgb, _ = ops.composite_forward(*scenes[1].query_points(pts, dirs), delta)
+        parts.append(rgb)
+    assert torch.equal(torch.cat(parts), a)

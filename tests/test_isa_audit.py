@@ -6,7 +6,6 @@ audit (scripts/audit_asm_loads.py) walks the emitted ISA and fails if any instru
 of a hand-issued read before a covering `s_waitcnt lgkmcnt`, or if compiler-generated code uses M0, which the
 LDS-DMA pieces overwrite without restoring."""
 import os
-import re
 import subprocess
 import sys
 
@@ -28,8 +27,9 @@ def test_hand_issued_reads_are_waited_for(name, tmp_path):
     assert out.returncode == 0, out.stdout[-2000:]
     assert "hand-issued LDS reads, 0 problems" in out.stdout
     assert int(out.stdout.rsplit(":", 1)[1].split()[0]) > 100      # the audit really saw the reads
-    # no kernel of these files may spill: a scratch reload is a VMEM load whose vmcnt wait also waits for the weight DMA
-    # (mlp_layered: a few dead scalar spill slots of the pass programs; the three-position-block narrow forward --
-    # pos_dim 65..96 with feat_dim <= 128 -- spills ~30 registers, the other instances none)
-    scratch = [int(x) for x in re.findall(r"; ScratchSize: (\d+)", asm.read_text())]
-    assert scratch and max(scratch) <= (160 if name == "mlp_layered" else 0), scratch
+    # no kernel of these files may spill beyond what scratch_allow.txt lists for ITS symbol: a scratch reload is a VMEM load
+    # whose vmcnt wait also waits for the weight DMA (scripts/audit_scratch.py; a file-wide allowance would hide a new
+    # spill in any of the layered family's ~50 instances)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "audit_scratch.py"), str(asm)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]

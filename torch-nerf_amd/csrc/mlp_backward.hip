@@ -20,6 +20,7 @@
 //     scalar sums into the flat gradient blob (state_dict layout).  No atomics anywhere: gradients are
 //     reproducible bit for bit.
 #include <stdlib.h>
+#include <mutex>
 #include <vector>
 
 #include "mlp_device.h"
@@ -848,6 +849,43 @@ int64_t dw_items_scratch_bytes(int n_items) {
     return list + 4 * (int64_t)(512 + n_items) * (256 * 256 + SLICE_EXTRA);
 }
 
+// The descriptor list travels through a small ring of PINNED host buffers: a copy from pageable memory makes the runtime
+// stage the bytes synchronously inside hipMemcpyAsync (host blocked, not capturable into a graph, and correct only
+// because of that staging).  A slot is reused after the event recorded behind its copy has completed.
+namespace {
+struct ListRing {
+    static constexpr int SLOTS = 8;
+    char *buf[SLOTS] = {};
+    size_t cap[SLOTS] = {};
+    hipEvent_t done[SLOTS] = {};
+    bool used[SLOTS] = {};
+    int next = 0;
+    std::mutex mu;
+    // -> a pinned buffer of >= bytes whose previous upload (if any) has finished; *slot for mark()
+    char *take(size_t bytes, int *slot) {
+        std::lock_guard<std::mutex> lock(mu);
+        const int k = next;
+        next = (next + 1) % SLOTS;
+        if (used[k] && hipEventSynchronize(done[k]) != hipSuccess) return nullptr;
+        if (cap[k] < bytes) {
+            if (buf[k]) (void)hipHostFree(buf[k]);
+            buf[k] = nullptr; cap[k] = 0;
+            const size_t want = (bytes + 65535) & ~(size_t)65535;
+            if (hipHostMalloc(reinterpret_cast<void **>(&buf[k]), want, hipHostMallocDefault) != hipSuccess) return nullptr;
+            cap[k] = want;
+        }
+        if (!done[k] && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) != hipSuccess) return nullptr;
+        *slot = k;
+        return buf[k];
+    }
+    void mark(int slot, hipStream_t s) {
+        std::lock_guard<std::mutex> lock(mu);
+        used[slot] = hipEventRecord(done[slot], s) == hipSuccess;
+    }
+};
+ListRing g_list_ring;
+}  // namespace
+
 int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int64_t scratch_bytes, hipStream_t s) {
     const int n = (int)items.size();
     if (n == 0 || M <= 0) return NERF_OK;
@@ -863,9 +901,12 @@ int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int
         if (it.w_dst < base) base = it.w_dst;
         if (it.b_dst && it.b_dst < base) base = it.b_dst;
     }
-    std::vector<char> host(16 + (size_t)n * sizeof(GemmDesc));
-    GemmList *hdr = reinterpret_cast<GemmList *>(host.data());
-    GemmDesc *G = reinterpret_cast<GemmDesc *>(host.data() + sizeof(GemmList));
+    const size_t host_bytes = 16 + (size_t)n * sizeof(GemmDesc);
+    int slot = 0;
+    char *host = g_list_ring.take(host_bytes, &slot);
+    if (!host) return nerf::fail(NERF_ERR_LAUNCH, "nerf_mlp_layered_backward: pinned staging buffer for the dW item list");
+    GemmList *hdr = reinterpret_cast<GemmList *>(host);
+    GemmDesc *G = reinterpret_cast<GemmDesc *>(host + sizeof(GemmList));
     static_assert(sizeof(GemmList) == 16, "header size");
     int64_t units = 0;
     for (int k = 0; k < n; ++k) {
@@ -908,12 +949,12 @@ int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int
         G[k].first_block = fb; G[k].num_slices = lb - fb + 1; G[k].partial_off = off;
         off += (int64_t)G[k].num_slices * ((int64_t)G[k].a_width * G[k].x_width + SLICE_EXTRA);
     }
-    const int64_t list_bytes = ((int64_t)host.size() + 255) & ~(int64_t)255;
+    const int64_t list_bytes = ((int64_t)host_bytes + 255) & ~(int64_t)255;
     if (list_bytes + 4 * off > scratch_bytes)
         return nerf::fail(NERF_ERR_ARG, "nerf_mlp_layered_backward: workspace too small for the dW partial tiles");
-    // pageable source: the runtime stages the bytes before it returns, so `host` may go out of scope
-    if (hipMemcpyAsync(scratch, host.data(), host.size(), hipMemcpyHostToDevice, s) != hipSuccess)
+    if (hipMemcpyAsync(scratch, host, host_bytes, hipMemcpyHostToDevice, s) != hipSuccess)
         return nerf::check_launch("nerf_mlp_layered_backward: item list upload");
+    g_list_ring.mark(slot, s);
     const GemmList *list = static_cast<const GemmList *>(scratch);
     float *partial = reinterpret_cast<float *>(static_cast<char *>(scratch) + list_bytes);
     hipLaunchKernelGGL(mlp_bwd_dw_list_kernel, dim3((unsigned)B), dim3(256), DW_LDS_BYTES, s, list, partial, M);

@@ -167,7 +167,7 @@ struct Pipe {
         ++issued;
         do {
             issue_pos = (issue_pos + 1 == n_pairs) ? 0 : issue_pos + 1;
-        } while ((skip_mask >> issue_pos) & 1ull);
+        } while (issue_pos < 64 && ((skip_mask >> issue_pos) & 1ull));   // (positions >= 64 cannot be skipped: a 64-bit mask)
     }
     __device__ __forceinline__ void issue() {
 #pragma unroll

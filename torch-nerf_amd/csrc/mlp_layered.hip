@@ -744,7 +744,10 @@ constexpr int REG_LDS = RING_SLOTS * CHUNK_BYTES + 16384;   // ring + the consta
 __host__ __device__ inline bool reg_ok(const Dims &D) {
     // (four position blocks -- coord_encode_level 16: pos_dim 99 -- where the encoded position is one sample block or
     // the network is narrow; with two sample blocks of 128 features its 128 registers do not fit)
-    return ((D.Fp == 64 && D.Hp == 32) || (D.Fp == 128 && D.Hp == 64) || (D.Fp == 256 && D.Hp == 128)) && D.Dp == 32 &&
+    // (two direction blocks -- dir_encode_level 5..10: view_dir_dim 33..63 -- for the 256-feature forward only: its
+    // reverse chain is the general one, and the narrow networks are not reachable from the reference's configs)
+    return ((D.Fp == 64 && D.Hp == 32) || (D.Fp == 128 && D.Hp == 64) || (D.Fp == 256 && D.Hp == 128)) &&
+           (D.Dp == 32 || (D.Dp == 64 && D.Fp == 256)) &&
            D.Pp <= (D.Fp == 128 ? 96 : 128) && D.c_floats() <= 4096;
 }
 
@@ -801,7 +804,8 @@ __device__ __forceinline__ void run_blocks(f32x16 *acc0, f32x16 *acc1, Seq seq, 
 }
 
 // (NSB sample blocks, NFB feature blocks) per wavefront: (1, 8) = feat_dim 225..256, (2, 4) = 97..128, (2, 2) = 33..64
-template <int NSB, int NFB, int PB, bool RECORD>
+// DB = 32-wide blocks of the encoded direction (1: view_dir_dim <= 32; 2: <= 64, instantiated for NSB = 1 only)
+template <int NSB, int NFB, int PB, bool RECORD, int DB = 1>
 __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
     // fc_9's pass is packed with at least two accumulator blocks per k-block (pass_nfb)
     constexpr int HB = NFB / 2, KPC = 8 / NFB, S9 = HB < 2 ? 2 : HB, KPC9 = 8 / S9, FP = 32 * NFB, HP = 32 * HB, TILE = 128 * NSB;
@@ -906,9 +910,11 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) save_plane<NFB, true>(plane(D.r_h(8)), FP, m[sb], h, act[sb]);
             }
-            f32x16 de[NSB];       // (fetched here, L2-hot, instead of living in 16 NSB registers through fc_in .. fc_8)
+            f32x16 de[NSB][DB];   // (fetched here, L2-hot, instead of living in 16 NSB DB registers through fc_in .. fc_8)
 #pragma unroll
-            for (int sb = 0; sb < NSB; ++sb) de[sb] = load_block(plane(D.r_de()) + (row0 + 32 * sb) * 32, 0, i, h);
+            for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+                for (int b = 0; b < DB; ++b) de[sb][b] = load_block(plane(D.r_de()) + (row0 + 32 * sb) * (32 * DB), b, i, h);
 #pragma unroll
             for (int fb = 0; fb < HB; ++fb)
 #pragma unroll
@@ -919,8 +925,8 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
                         a9[sb][fb][4 * q + 0] = v.x; a9[sb][fb][4 * q + 1] = v.y; a9[sb][fb][4 * q + 2] = v.z; a9[sb][fb][4 * q + 3] = v.w;
                     }
                 }
-            auto Cat9 = [&](int sb, int k) -> const f32x16 & { return k < NFB ? act[sb][k < NFB ? k : 0] : de[sb]; };
-            run_blocks<NSB, HB, S9, KPC9, NFB + 1, false, false>(a9[0], a9[NSB - 1], Cat9, none, w, lds, pipe, offq);
+            auto Cat9 = [&](int sb, int k) -> const f32x16 & { return k < NFB ? act[sb][k < NFB ? k : 0] : de[sb][k >= NFB ? k - NFB : 0]; };
+            run_blocks<NSB, HB, S9, KPC9, NFB + DB, false, false>(a9[0], a9[NSB - 1], Cat9, none, w, lds, pipe, offq);
         }
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
@@ -1148,9 +1154,9 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSB, int NFB, int PB>
+template <int NSB, int NFB, int PB, int DB = 1>
 int launch_reg_fwd(bool record, const WideArgs &a, hipStream_t s) {
-    auto kern = record ? reg_forward_kernel<NSB, NFB, PB, true> : reg_forward_kernel<NSB, NFB, PB, false>;
+    auto kern = record ? reg_forward_kernel<NSB, NFB, PB, true, DB> : reg_forward_kernel<NSB, NFB, PB, false, DB>;
     static nerf::DeviceMask configured[2] = {{0}, {0}};
     if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), REG_LDS, configured[record],
                                           "nerf_mlp_layered: LDS attribute (register-resident forward)"))
@@ -1167,6 +1173,9 @@ int launch_reg_forward(bool record, const WideArgs &a, hipStream_t s) {
              : pb == 3 ? launch_reg_fwd<2, 2, 3>(record, a, s) : launch_reg_fwd<2, 2, 4>(record, a, s);
     if (a.D.Fp == 128)
         return pb == 1 ? launch_reg_fwd<2, 4, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<2, 4, 2>(record, a, s) : launch_reg_fwd<2, 4, 3>(record, a, s);
+    if (a.D.Dp == 64)
+        return pb == 1 ? launch_reg_fwd<1, 8, 1, 2>(record, a, s) : pb == 2 ? launch_reg_fwd<1, 8, 2, 2>(record, a, s)
+             : pb == 3 ? launch_reg_fwd<1, 8, 3, 2>(record, a, s) : launch_reg_fwd<1, 8, 4, 2>(record, a, s);
     return pb == 1 ? launch_reg_fwd<1, 8, 1>(record, a, s) : pb == 2 ? launch_reg_fwd<1, 8, 2>(record, a, s)
          : pb == 3 ? launch_reg_fwd<1, 8, 3>(record, a, s) : launch_reg_fwd<1, 8, 4>(record, a, s);
 }
@@ -1361,6 +1370,16 @@ NERF_API int64_t nerf_mlp_layered_plane(const nerf_net_t *net, int64_t rows, int
     return z.consts + z.fwd_stream + 4 * (int64_t)off * lrows(rows);
 }
 
+// How many <= 256 x 256 windows the dW pass cuts the eleven layers into: the same enumeration as the `add` calls of
+// nerf_mlp_layered_backward (windows of a (n_w x x_w) product: ceil(n_w / 256) * ceil(x_w / 256)), so that the
+// workspace is sized for the list that will really be built -- also for very wide pos_dim / view_dir_dim.
+static int dw_item_budget(const Dims &D) {
+    auto win = [](int n_w, int x_w) { return ((n_w + 255) / 256) * ((x_w + 255) / 256); };
+    int n = win(D.Fp, D.Pp);                                   // fc_in
+    for (int l = 1; l <= 8; ++l) n += win(D.Fp, D.Fp) + (l == 5 ? win(D.Fp, D.Pp) : 0);
+    return n + win(D.Hp, D.Fp) + win(D.Hp, D.Dp);              // fc_9: features, then the direction
+}
+
 // workspace = [reverse stream (with the input-gradient passes)][gradient planes][thin partials][dW scratch]
 NERF_API int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t M) {
     nerf_net_t d;
@@ -1369,13 +1388,12 @@ NERF_API int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t
     const Dims D = make_dims(d);
     const Sizes z = sizes(D, M, true, 1);
     const int64_t thin = align256b(8 * (int64_t)THIN_SLICES * (D.Fp + 3 * D.Hp + 4));
-    const int items = 64 * ((D.Fp + 255) / 256) * ((D.Fp + 255) / 256) + 64;
-    return z.dx_stream + z.planes + thin + nerf::dw_items_scratch_bytes(items) + 65536;
+    return z.dx_stream + z.planes + thin + nerf::dw_items_scratch_bytes(dw_item_budget(D)) + 65536;
 }
 
 NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params, const float *pos,
                                       const float *view_dir, int64_t M, float *sigma, float *rgb, void *record,
-                                      int64_t record_rows, nerf_stream_t stream) {
+                                      int64_t record_rows, int keep_record, nerf_stream_t stream) {
     nerf_net_t d;
     if (nerf::net_describe(net, d) < 0) return NERF_ERR_ARG;
     NERF_REQUIRE(M >= 0, "nerf_mlp_layered_forward: negative M");
@@ -1383,13 +1401,15 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
     NERF_REQUIRE(params && pos && view_dir && sigma && rgb && record && record_rows > 0,
                  "nerf_mlp_layered_forward: null pointer");
     NERF_REQUIRE(M < (int64_t)1 << 31, "nerf_mlp_layered_forward: more than 2^31 samples per call");
+    NERF_REQUIRE(!keep_record || record_rows >= M, "nerf_mlp_layered_forward: a kept record needs record_rows >= M");
+    const bool recording = keep_record != 0;
     const Dims D = make_dims(d);
     hipStream_t s = nerf::as_stream(stream);
     int64_t chunk = record_rows < M ? record_rows : M;
     const Sizes z = sizes(D, chunk, false, 0);
     // an inference call on a network that fits the register file touches only the two input planes of its scratch:
     // the same bytes hold recw / (Pp + Dp) times the rows (fewer, longer launches: 12+ tiles per CU instead of one)
-    if (reg_ok(D) && record_rows < M) {
+    if (reg_ok(D) && !recording) {
         const int64_t fit = lrows(record_rows) * D.recw() / (D.Pp + D.Dp) / 256 * 256;
         chunk = fit < M ? fit : M;
     }
@@ -1413,10 +1433,10 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
         WideArgs a = {};
         a.D = D; a.stream = reinterpret_cast<const char *>(fstream); a.consts = consts;
         a.rec = planes; a.grad = nullptr; a.M = rows; a.MP = MP;
-        a.n_passes = fwd_num_passes(D); a.n_pairs = pa.n_pairs; a.inputs = 0; a.record = record_rows >= M;
+        a.n_passes = fwd_num_passes(D); a.n_pairs = pa.n_pairs; a.inputs = 0; a.record = recording;
         a.sigma = sigma + r0; a.rgb = rgb + 3 * r0;
-        // networks that fit the register file: planes written only when the whole batch is recorded for a backward
-        if (int rc = reg_ok(D) ? launch_reg_forward(record_rows >= M, a, s) : launch_program(false, a, s)) return rc;
+        // networks that fit the register file: planes written only when the batch is recorded for a backward
+        if (int rc = reg_ok(D) ? launch_reg_forward(recording, a, s) : launch_program(false, a, s)) return rc;
     }
     return NERF_OK;
 }
@@ -1503,5 +1523,7 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
     }
     add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_h(8)), D.Fp, D.F, 0, true);
     add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_de()), D.Dp, D.E_d, D.F, false);
-    return nerf::run_dw_items(items, M, dw_scratch, nerf::dw_items_scratch_bytes((int)items.size()) + 65536, s);
+    // (the bytes really left in the workspace nerf_mlp_layered_workspace_bytes sized, not a figure derived from the list)
+    NERF_REQUIRE((int)items.size() <= dw_item_budget(D), "nerf_mlp_layered_backward: more dW windows than the workspace was sized for");
+    return nerf::run_dw_items(items, M, dw_scratch, nerf::dw_items_scratch_bytes(dw_item_budget(D)) + 65536, s);
 }

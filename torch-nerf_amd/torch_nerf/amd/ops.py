@@ -444,8 +444,11 @@ LAYERED_INFERENCE_ROWS = 65536     # rows of activation scratch an inference cal
 
 
 def mlp_layered_forward(flat_params, pos, view_dir, net: Net, record: bool = False):
-    """NeRF.forward on pre-encoded inputs, one MFMA GEMM launch per layer (csrc/mlp_layered.hip).
-    -> (sigma (M,), rgb (M,3)[, record tensor])."""
+    """NeRF.forward on pre-encoded inputs through the layered family (csrc/mlp_layered.hip): ONE persistent launch
+    walks all eleven layers (register-resident for the widths reg_ok admits, plane-parked otherwise).
+    record=True keeps the activation / ReLU-bit planes of all M rows for mlp_layered_backward; record=False is the
+    inference call: only scratch for LAYERED_INFERENCE_ROWS rows, and no planes written at all on register-resident
+    networks.  -> (sigma (M,), rgb (M,3)[, record tensor])."""
     lib = _lib.load()
     flat_params, pos, view_dir = _gpu(flat_params, "flat_params"), _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
     _check_rows(pos, view_dir, True, net)
@@ -460,7 +463,7 @@ def mlp_layered_forward(flat_params, pos, view_dir, net: Net, record: bool = Fal
     with torch.cuda.device(pos.device):
         end = _timed("mlp_layered_forward", M)
         _lib.check(lib.nerf_mlp_layered_forward(net.ref, _ptr(flat_params), _ptr(pos), _ptr(view_dir), M, _ptr(sigma),
-                                                _ptr(rgb), _ptr(rec), max(rows, 1), _stream()),
+                                                _ptr(rgb), _ptr(rec), max(rows, 1), int(bool(record)), _stream()),
                    "nerf_mlp_layered_forward")
         if end is not None:
             end.record()

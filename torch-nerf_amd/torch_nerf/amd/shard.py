@@ -21,6 +21,11 @@ _G1 = -7046029254386353131   # 0x9E3779B97F4A7C15
 _G2 = -3372029247567499371   # 0xD1342543DE82EF95
 
 
+# rays per launch of render_frame's kernel chain (non-fused networks): 16 384 x 192 samples x (pos_dim + view_dir_dim + 12)
+# floats of points / directions / encodings stay under ~2 GB for the widest yaml-reachable encoders
+CHAIN_RAYS_PER_LAUNCH = 16384
+
+
 def _lsr(x: torch.Tensor, k: int) -> torch.Tensor:
     """logical shift right on int64"""
     return (x >> k) & ((1 << (64 - k)) - 1)
@@ -109,11 +114,25 @@ def allreduce_gradients(parameters, group: Optional[dist.ProcessGroup] = None, a
         off += n
 
 
+def _scene_parts(x):
+    """(network, scene | None): render_frame takes the two NeRF modules (encoders inferred from their widths) or the two
+    scene primitives the runners hold (runner_utils.py:872-908 passes default_scene / fine_scene)."""
+    field = getattr(x, "radiance_field", None)
+    return (x, None) if field is None else (field, x)
+
+
 @torch.no_grad()
 def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, project_to_ndc: bool, seed: int,
                  group: Optional[dist.ProcessGroup] = None, rays_per_launch: int = 131072,
-                 bf16: bool = False, single_rank: bool = False) -> torch.Tensor:
+                 bf16: bool = False, single_rank: bool = False, stats: Optional[dict] = None) -> torch.Tensor:
     """Full frame (H*W, 3) on every rank; each rank renders only its pixel range on its own GPU.
+    stats (optional dict) receives what a slow N-GPU frame is diagnosed from: this rank's pixel range, its number of
+    launches and two GPU events bracketing its own rendering, the collective excluded (`render_events`).
+    coarse_net / fine_net: NeRF modules, or PrimitiveCube scenes (network + encoders).  Networks of the fused family
+    behind PositionalEncoders run ONE kernel per pass and launch; every other combination the scene can evaluate --
+    coord_encode_level >= 11, dir_encode_level >= 5, signal_encoder: sh -- runs the kernel chain sampling ->
+    scene.query_points (encoder kernels + the layered network kernel) -> integral per launch, in smaller launches
+    (the encodings of a launch are materialised in HBM).  Same pixel ranges, same counter draws, same all-gather.
     single_rank=True: the calling rank renders the whole frame alone, no collective (the 1-GPU image a sharded
     image must equal bit for bit)."""
     from torch_nerf.amd import ops
@@ -127,27 +146,51 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
     lo, hi = shard_range(total, rank, world)
     sampler = StratifiedSampler()
     t_bins, ps = sampler._create_t_bins(camera.t_near, camera.t_far, n_coarse, device)
-    _, flat_c, packed_c = coarse_net._stream()
-    _, flat_f, packed_f = fine_net._stream()
-    spec_c, spec_f = coarse_net.inferred_net(), fine_net.inferred_net()   # PositionalEncoders inferred from the widths
-    if spec_c is None or spec_f is None:
-        raise RuntimeError("render_frame runs the fused render pass: feat_dim 256, pos_dim <= 64, view_dir_dim <= 32 "
-                           "behind PositionalEncoders")
-    if bf16:  # BASELINE configs[2]: bf16 weights / layer inputs on the bf16 MFMA path
-        packed_c, packed_f = ops.mlp_pack_bf16(flat_c, spec_c), ops.mlp_pack_bf16(flat_f, spec_f)
+    (coarse_net, coarse_scene), (fine_net, fine_scene) = _scene_parts(coarse_net), _scene_parts(fine_net)
+    spec_c = coarse_scene.fused_net() if coarse_scene is not None else coarse_net.inferred_net()
+    spec_f = fine_scene.fused_net() if fine_scene is not None else fine_net.inferred_net()
+    fused = spec_c is not None and spec_f is not None
+    if not fused and (coarse_scene is None or fine_scene is None):
+        raise RuntimeError("render_frame: these networks are outside the fused family (feat_dim 256, pos_dim <= 64, "
+                           "view_dir_dim <= 32 behind PositionalEncoders); pass the scene primitives (network + "
+                           "encoders) instead of the bare networks so that the kernel chain can encode for them")
+    if bf16 and not fused:
+        raise RuntimeError("render_frame(bf16=True): the bf16 kernel serves the fused family only")
+    if fused:
+        _, flat_c, packed_c = coarse_net._stream()
+        _, flat_f, packed_f = fine_net._stream()
+        if bf16:  # BASELINE configs[2]: bf16 weights / layer inputs on the bf16 MFMA path
+            packed_c, packed_f = ops.mlp_pack_bf16(flat_c, spec_c), ops.mlp_pack_bf16(flat_f, spec_f)
+    else:
+        rays_per_launch = min(rays_per_launch, CHAIN_RAYS_PER_LAUNCH)
     out = torch.empty((hi - lo, 3), dtype=torch.float32, device=device)
     # equal launches of at most rays_per_launch rays (a multiple of 4: the fused pass walks bunches of four rays): the
     # persistent kernel then ends every launch with the same, small, last-round imbalance instead of one short tail
     launches = max(1, -(-(hi - lo) // max(1, rays_per_launch)))
     per_launch = -(-(hi - lo) // launches)
     per_launch = min(max(4, (per_launch + 3) // 4 * 4), max(4, rays_per_launch))
+    if stats is not None:
+        stats.update(rank=rank, first=lo, rays=hi - lo, launches=len(range(lo, hi, per_launch)), rays_per_launch=per_launch,
+                     fused=fused, render_events=(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+        stats["render_events"][0].record()
     for first in range(lo, hi, per_launch):
         n = min(per_launch, hi - first)
         bundle = sampler.generate_rays_from_pixels(camera, project_to_ndc, first=first, count=n, device=device)
         u1c, u1, u2, u3 = ray_draws(seed, first, n, n_coarse, n_fine, device)
-        rgb, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, bf16=bf16, net=spec_c)
-        if n_fine > 0:     # n_fine == 0: coarse-only frame (BASELINE configs[0])
-            rgb, _ = ops.render_rays(packed_f, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1, weights=w, u2=u2,
-                                     u3=u3, bf16=bf16, net=spec_f)
+        if fused:
+            rgb, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, bf16=bf16, net=spec_c)
+            if n_fine > 0:     # n_fine == 0: coarse-only frame (BASELINE configs[0])
+                rgb, _ = ops.render_rays(packed_f, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1, weights=w, u2=u2,
+                                         u3=u3, bf16=bf16, net=spec_f)
+        else:
+            pts, dirs, delta = ops.sample_stratified(bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c)
+            sigma, radiance = coarse_scene.query_points(pts, dirs)
+            rgb, w = ops.composite_forward(sigma, radiance, delta)
+            if n_fine > 0:
+                pts, dirs, delta = ops.sample_hierarchical(bundle.ray_origin, bundle.ray_dir, t_bins, ps, w, u1, u2, u3)
+                sigma, radiance = fine_scene.query_points(pts, dirs)
+                rgb, _ = ops.composite_forward(sigma, radiance, delta)
         out[first - lo: first - lo + n] = rgb
+    if stats is not None:
+        stats["render_events"][1].record()
     return out if single_rank else gather_image(out, total, group)

@@ -12,8 +12,9 @@ optimizer visibility); they are never called.  Two kernel families sit underneat
     include_input combination the yaml can express (runner_utils.py:584-612): the register-resident kernels of
     csrc/mlp_forward.hip / mlp_backward.hip behind torch_nerf.amd.ops.NerfMLPFunction
     (gradients w.r.t. the inputs included: three thin GEMMs more in the dX chain)
-  * any other NeRF(pos_dim, view_dir_dim, feat_dim): one launch per layer, csrc/mlp_layered.hip behind
-    ops.NerfLayeredFunction
+  * any other NeRF(pos_dim, view_dir_dim, feat_dim): the layered family, csrc/mlp_layered.hip behind
+    ops.NerfLayeredFunction -- one persistent launch per forward / reverse chain (register-resident for feat_dim 256
+    with pos_dim <= 128 and view_dir_dim <= 64, i.e. every coord_encode_level / dir_encode_level the yaml can name)
 """
 from typing import Tuple
 
@@ -120,7 +121,9 @@ class NeRF(nn.Module):
         record = self._wants_grad(params)
         input_grads = torch.is_grad_enabled() and (pos.requires_grad or view_dir.requires_grad)
         if self.bf16_inference and not (record or input_grads):
-            self.warn_bf16_ignored()    # pre-encoded inputs: the bf16 kernel encodes raw points itself
+            # pre-encoded inputs: the bf16 kernel takes RAW points (it encodes them itself), so this entry is fp32 for
+            # every network -- the scene's fused query (forward_fused / render_scene) is the bf16 path
+            self.warn_bf16_ignored()
         if self._net.fused:    # (gradients w.r.t. the inputs come out of the same dX chain)
             return ops.NerfMLPFunction.apply(pos, view_dir, True, record or input_grads, packed, flat, self._net, *params)
         return ops.NerfLayeredFunction.apply(pos, view_dir, record or input_grads, flat, self._net, *params)

@@ -108,6 +108,8 @@ class VolumeRenderer(object):
         origin, direction = ray_bundle.ray_origin.to(dev), ray_bundle.ray_dir.to(dev)
         u1, u2, u3 = self.sampler.draw_uniforms(origin.shape[0], n_coarse, n_fine if hierarchical else 0, dev)
         bf16 = bool(getattr(net, "bf16_inference", False)) and spec.bf16_ok
+        if getattr(net, "bf16_inference", False) and not bf16:
+            net.warn_bf16_ignored(spec)          # never silently fp32 when bf16 was asked for
         if bf16:
             packed = net._stream_bf16()
         if not hierarchical:
