@@ -291,7 +291,10 @@ def test_training_converges_on_procedural_scene():
     first, last = mse[:10].mean(), mse[-50:].mean()
     psnr_first, psnr_last = -10 * np.log10(first), -10 * np.log10(last)
     assert np.isfinite(mse).all()
-    assert psnr_last > psnr_first + 6.0 and psnr_last > 17.0, (psnr_first, psnr_last)
+    print("convergence test: psnr_first", psnr_first, "psnr_last", psnr_last)
+    # measured with this tree's kernels: 7.5 dB -> 23.1 dB in 600 steps; the floor is that minus 1 dB (was 17 dB, set with
+    # round 1's kernels).  The long run -- 6000 steps, 37-41 dB held out -- is profiles/r05_train_procedural_6000.json
+    assert psnr_last > psnr_first + 6.0 and psnr_last > 22.0, (psnr_first, psnr_last)
 
 
 def _dp_worker(rank, world, port, q):

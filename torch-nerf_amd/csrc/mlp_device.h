@@ -117,6 +117,11 @@ __device__ __forceinline__ float relu1(float x) {
 #define X_DMA_POLICY ""      // A/B knob: cache-policy suffix of the weight-stream loads (" nt", " sc0", " sc1")
 #endif
 __device__ __forceinline__ void lds_dma_16s(const char *src, unsigned lane_off, unsigned lds_dst) {
+#ifdef X_DMA_BUILTIN   // A/B: the compiler's own LDS-DMA -- it sets M0 and counts vmcnt itself
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane_off),
+                                     (__attribute__((address_space(3))) void *)(uintptr_t)lds_dst, 16, 0, 0);
+    return;
+#endif
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
@@ -231,6 +236,10 @@ struct PlaneStore {
     __device__ __forceinline__ void issue(int s) const {
         const int fb = s >> 2, q = s & 3;
         const f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
+#ifdef X_STORE_PLAIN   // A/B: a store hipcc can see (its own hazard recognizer, its own address form)
+        *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(tile + (uint64_t)fb * 4096u) + (unit16 ^ (32u * q)) + q * 1024) = v;
+        return;
+#endif
         // (s_nop 4 in front: the scalar base may come straight out of a v_readfirstlane / SALU add -- see save_plane();
         // s_nop 1 behind: wide-store data hazard, inside the statement)
         asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
@@ -457,6 +466,10 @@ __device__ __forceinline__ void save_plane(float *plane, int width, int64_t m, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = {blk[fb][4 * q], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]};
+#ifdef X_STORE_PLAIN
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + (unit16 ^ (32u * q)) + q * 1024) = v;
+            continue;
+#endif
             // The scalar base comes out of v_readfirstlane (a VALU write of an SGPR), and gfx950 wants 5 wait states
             // between that and a VMEM instruction reading the SGPR.  hipcc's hazard recognizer cannot see the VMEM
             // instruction inside the asm, so the FIRST store of the call carries the wait states itself (measured
