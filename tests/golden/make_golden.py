@@ -219,6 +219,14 @@ def grad_digest(net):
         d[k + ".sum"] = np.array([np.sum(g.astype(np.float64))])
         d[k + ".head"] = g[:GRAD_SLICE].copy()
         d[k + ".stride"] = g[:: max(1, g.size // GRAD_SLICE)][:GRAD_SLICE].copy()
+        # every element takes part in two more numbers (round 5): the sums along both axes of a weight gradient (a wrong
+        # element anywhere moves one row sum and one column sum), and bias gradients whole
+        if p.grad.ndim == 2:
+            g2 = p.grad.detach().numpy().astype(np.float64)
+            d[k + ".rowsum"] = g2.sum(axis=1)
+            d[k + ".colsum"] = g2.sum(axis=0)
+        else:
+            d[k + ".full"] = g.copy()
     return d
 
 

@@ -19,6 +19,18 @@ def check_grad_digest(flat_grad, g, prefix, rtol, atol_scale, norm_rtol=1e-4, di
         np.testing.assert_allclose(v[::step][:strided.size], strided, rtol=rtol, atol=atol, err_msg=k)
         norm = np.sqrt(np.sum(v.astype(np.float64) ** 2))
         assert abs(norm - norm_ref) <= norm_rtol * norm_ref + 1e-12, (k, norm, norm_ref)
+        # sums along both axes of a weight gradient / the whole bias gradient: EVERY element takes part in these
+        full = grads[k]
+        if prefix + k + ".rowsum" in g.files:
+            f64 = full.astype(np.float64)
+            for axis, name in ((1, ".rowsum"), (0, ".colsum")):
+                ref = g[prefix + k + name]
+                # n element errors, partly coherent (a row of dW is one dY value times a vector: its error scales the row):
+                # 4 sqrt(n) per-element allowances -- an element off by more than that is seen wherever it sits
+                tol = rtol * np.abs(ref) + 4.0 * atol * np.sqrt(full.shape[axis])
+                assert np.all(np.abs(f64.sum(axis=axis) - ref) <= tol), (k, name, float(np.abs(f64.sum(axis=axis) - ref).max()))
+        if prefix + k + ".full" in g.files:
+            np.testing.assert_allclose(v, g[prefix + k + ".full"], rtol=rtol, atol=atol, err_msg=k + " (whole)")
 
 
 # tests/golden/f11_net_variants.npz: tag -> (coord_encode_level, dir_encode_level, include_input, feat_dim)

@@ -72,6 +72,7 @@ def test_fused_family_record_forward_and_backward_are_bit_reproducible(name, key
 
 
 LAYERED_CASES = [("narrow-128", (63, 27, 128)), ("narrow-3-pos-blocks", (75, 27, 100)), ("reg-256-level-12", (75, 27, 256)),
+                 ("reg-256-dir-level-5", (63, 33, 256)), ("reg-256-level-16-dir-level-10", (99, 63, 256)),
                  ("wide-512", (63, 27, 512)),
                  ("ragged-160", (40, 40, 160)), ("thin-64", (75, 39, 64)), ("reg-64", (63, 27, 64))]
 

@@ -180,13 +180,17 @@ def test_full_tensor_vs_oracle(oracle, golden, tag, M):
                                     ((63, 27, 512), 300), ((40, 40, 160), 333), ((63, 27, 96), 129),
                                     ((63, 27, 64), 700), ((75, 27, 40), 257), ((21, 15, 50), 130), ((75, 39, 64), 300),
                                     ((63, 27, 64), 1), ((63, 27, 128), 31), ((63, 27, 512), 33), ((75, 27, 256), 2),
-                                    ((99, 27, 256), 300), ((99, 27, 64), 515), ((99, 27, 128), 129)])
+                                    ((99, 27, 256), 300), ((99, 27, 64), 515), ((99, 27, 128), 129),
+                                    # two direction blocks in the register-resident forward (round 5: dir_encode_level 5..10)
+                                    ((63, 33, 256), 1000), ((75, 39, 256), 513), ((99, 63, 256), 300), ((27, 64, 256), 129)])
 def test_layered_family_any_widths_vs_oracle(oracle, dims, M):
     """Widths the fixtures do not hold, every element against the CPU oracle under the kernel's own ReLU decisions:
     the register-resident kernels (feat_dim 33..64 and 97..128 with two sample blocks per wavefront, feat_dim 225..256 with
     pos_dim 65..128 = coord_encode_level 12..16 -- one to four position blocks, ragged feat_dim 100 / 230) and
     the general plane-parked kernel (feat_dim 512: two passes per layer; 160: a ragged
-    pass; view_dir_dim 40: two direction blocks), forward, parameter gradients and input gradients."""
+    pass; view_dir_dim 40: two direction blocks), forward, parameter gradients and input gradients.  (63, 33, 256) =
+    dir_encode_level 5 and the other view_dir_dim 33..64 cases with feat_dim 256 take reg_forward_kernel<1, 8, PB, RECORD, 2>
+    (two direction blocks, every PB)."""
     from helpers import assert_grads_match_given_masks, layered_masks
     e_p, e_d, feat = dims
     rng = np.random.RandomState(M + feat)
@@ -216,7 +220,7 @@ def test_layered_family_any_widths_vs_oracle(oracle, dims, M):
         np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * np.abs(b).max())
 
 
-@pytest.mark.parametrize("dims", [(63, 27, 64), (63, 27, 128), (75, 27, 256), (63, 27, 512), (75, 39, 64)])
+@pytest.mark.parametrize("dims", [(63, 27, 64), (63, 27, 128), (75, 27, 256), (63, 27, 512), (75, 39, 64), (63, 33, 256)])
 def test_layered_inference_walks_the_batch_in_chunks(monkeypatch, dims):
     """An inference call (nothing recorded) walks the batch through a scratch of LAYERED_INFERENCE_ROWS rows -- networks
     whose activations stay in registers take longer chunks out of the same bytes (only the two input planes are
