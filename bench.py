@@ -712,8 +712,9 @@ def encoder_variants_leg(device, local_rank, steps, warmup):
     name beyond the shipped 10 / 4 (configs/signal_encoder/positional_encoding.yaml:2-3, sh.yaml; runner_utils.py:584-612
     builds NeRF(coord_enc.out_dim, dir_enc.out_dim) behind them).  None of them fits the single-kernel render pass
     (pos_dim > 64, view_dir_dim > 32 or not a PositionalEncoder): each pass is the kernel chain.  `mlp_frac` = the
-    algorithmic MLP FLOPs of the step (UNPADDED widths) over the whole step time, of the fp32 MFMA peak; `frame` = the
-    800x800 frame through shard.render_frame's chain fallback."""
+    algorithmic MLP FLOPs of the step (UNPADDED widths) over the whole step time, of the fp32 MFMA peak; `train` = the
+    training step of the `train` leg on the same scenes (fwd + bwd + FusedAdam); `frame` = the 800x800 frame through
+    shard.render_frame's chain fallback."""
     import torch_nerf.src.network as network
     import torch_nerf.src.scene as scene
     from torch_nerf.src.signal_encoder import PositionalEncoder, SHEncoder
@@ -749,10 +750,36 @@ def encoder_variants_leg(device, local_rank, steps, warmup):
             img = shard.render_frame(cam, scenes[0], scenes[1], N_COARSE, N_FINE, False, seed=1, single_rank=True)
             torch.cuda.synchronize()
             dt_frame = time.perf_counter() - t0
-        flop = 2 * sum(o * i for o, i in synth.layer_shapes(ce.out_dim, de.out_dim, 256)) * RAYS * (2 * N_COARSE + N_FINE)
+        macs = sum(o * i for o, i in synth.layer_shapes(ce.out_dim, de.out_dim, 256))
+        flop = 2 * macs * RAYS * (2 * N_COARSE + N_FINE)
+        # the training step on the same scenes (record forward, integrator + MLP backward, FusedAdam), as the `train` leg
+        from torch_nerf.amd.optim import FusedAdam
+        opt = FusedAdam([p for sc in scenes for p in sc.radiance_field.parameters()], lr=5e-4, eps=1e-8)
+        mse, gt = torch.nn.MSELoss(), torch.rand((RAYS, 3), device=device)
+
+        def train_step(s):
+            opt.zero_grad(set_to_none=True)
+            c_rgb, c_idx, c_w = renderer.render_scene(scenes[0], RAYS, N_COARSE, False, local_rank, pixel_indices=pix[s])
+            f_rgb, _, _ = renderer.render_scene(scenes[1], RAYS, (N_COARSE, N_FINE), False, local_rank,
+                                                pixel_indices=c_idx, weights=c_w)
+            (mse(gt, c_rgb) + mse(gt, f_rgb)).backward()
+            opt.step()
+
+        for s in range(2):
+            train_step(s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(2, 2 + steps):
+            train_step(s % len(pix))
+        torch.cuda.synchronize()
+        dt_train = (time.perf_counter() - t0) / steps
+        # backward MACs: dW of every layer + dX of every layer input that is an activation (not the encodings)
+        bwd_macs = 2 * macs - (2 * ce.out_dim * 256 + de.out_dim * 128)
         out[tag] = {"network": f"NeRF({ce.out_dim}, {de.out_dim}, 256)", "path": "fused family, pre-encoded entry" if scenes[0].radiance_field._net.fused else "layered family",
                     "ms_per_step": dt * 1e3, "rays_per_s": RAYS / dt, "mlp_frac": flop / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                     "finite": bool(torch.isfinite(f_rgb).all()),
+                    "train": {"ms_per_step": dt_train * 1e3, "rays_per_s": RAYS / dt_train,
+                              "mlp_frac": 2 * (macs + bwd_macs) * RAYS * (2 * N_COARSE + N_FINE) / dt_train / 1e12 / FP32_MFMA_PEAK_TFLOPS},
                     "frame": {"ms": dt_frame * 1e3, "rays_per_s": H * W / dt_frame, "finite": bool(torch.isfinite(img).all())}}
     out["what"] = ("4096 rays x (64+128), fp32, coarse + fine render_scene per step (the headline step's two calls) behind "
                    "non-default encoders: kernel chain sampling -> encode -> network -> integral; frame = 800x800 via "

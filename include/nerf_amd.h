@@ -151,7 +151,9 @@ int nerf_mlp_backward(const nerf_net_t *net, const void *packed, const float *pa
                       void *workspace, nerf_stream_t stream);
 
 /* ---- a10 + a13, NERF_PATH_LAYERED (any pos_dim / view_dir_dim / feat_dim): NeRF.forward on PRE-ENCODED inputs
- * pos (M,pos_dim), view_dir (M,view_dir_dim).  ONE persistent launch per forward (and one per reverse chain): the
+ * pos (M,pos_dim), view_dir (M,view_dir_dim) (encoded != 0), or -- like nerf_mlp_forward -- on RAW points / directions
+ * (M,3) (encoded == 0; PrimitiveCube.query_points, cube.py:59-76, when nerf_net_t names both PositionalEncoders): the
+ * encodings are then written straight into the kernel's input planes, the (M, pos_dim) rows never exist.  ONE persistent launch per forward (and one per reverse chain): the
  * fused family's structure -- 128-sample tiles, weights streamed L2 -> LDS by LDS-DMA from a pre-packed, zero-padded
  * stream, v_mfma_f32_32x32x2_f32 with the weights as the A operand -- with the activations of a tile parked in HBM
  * planes between layers (a network of feat_dim 512 does not fit the register file); bias, ReLU / sigmoid and the two
@@ -174,7 +176,7 @@ int64_t nerf_mlp_layered_record_bytes(const nerf_net_t *net, int64_t rows);
 int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t M);
 int64_t nerf_mlp_layered_plane(const nerf_net_t *net, int64_t rows, int which, int *width);
 int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params, const float *pos, const float *view_dir,
-                             int64_t M, float *sigma, float *rgb, void *record, int64_t record_rows,
+                             int64_t M, int encoded, float *sigma, float *rgb, void *record, int64_t record_rows,
                              int keep_record, nerf_stream_t stream);
 int nerf_mlp_layered_backward(const nerf_net_t *net, const float *params, const float *pos, const float *view_dir,
                               int64_t M, const float *sigma, const float *rgb, const void *record,

@@ -127,12 +127,14 @@ def test_entry_points_refuse_what_they_cannot_serve_before_touching_the_gpu():
     assert lib.nerf_mlp_packed_bf16_bytes(other) > 0                                # run-time levels: served since round 4
     bad = net(63, 27, 256, 9, 1, 4, 1)
     assert lib.nerf_mlp_forward(bad, p, p, p, 4, 1, p, p, None, None) == ARG
-    assert lib.nerf_mlp_layered_forward(bad, p, p, p, 4, p, p, p, 4, 0, None) == ARG
+    assert lib.nerf_mlp_layered_forward(bad, p, p, p, 4, 1, p, p, p, 4, 0, None) == ARG
+    unknown = net(75, 27, 256, -1, 0, -1, 0)                                        # layered widths, encoders unknown: no raw entry
+    assert lib.nerf_mlp_layered_forward(unknown, p, p, p, 4, 0, p, p, p, 4, 0, None) == UNSUPPORTED and b"levels" in lib.nerf_amd_last_error()
     assert lib.nerf_shenc(p, 4, 6, p, None) == ARG and lib.nerf_shenc(p, 4, 0, p, None) == ARG
     assert lib.nerf_shenc_backward(p, p, 4, 9, p, None) == ARG
     # M = 0: nothing to do, nothing launched
     assert lib.nerf_mlp_forward(None, p, p, p, 0, 1, p, p, None, None) == OK
-    assert lib.nerf_mlp_layered_forward(f128, p, p, p, 0, p, p, p, 4, 0, None) == OK
-    assert lib.nerf_mlp_layered_forward(f128, p, p, p, 8, p, p, p, 4, 1, None) == ARG        # a kept record must hold every row
+    assert lib.nerf_mlp_layered_forward(f128, p, p, p, 0, 1, p, p, p, 4, 0, None) == OK
+    assert lib.nerf_mlp_layered_forward(f128, p, p, p, 8, 1, p, p, p, 4, 1, None) == ARG        # a kept record must hold every row
     assert lib.nerf_shenc(p, 0, 4, p, None) == OK and lib.nerf_posenc_backward(p, p, 0, 3, 10, 1, p, None) == OK
     assert lib.nerf_mlp_forward(None, p, p, p, -1, 1, p, p, None, None) == ARG

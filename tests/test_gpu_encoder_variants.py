@@ -149,3 +149,43 @@ def test_sharded_frame_through_the_kernel_chain(tag):
             rgb, _ = ops.composite_forward(*scenes[1].query_points(pts, dirs), delta)
         parts.append(rgb)
     assert torch.equal(torch.cat(parts), a)
+
+
+@pytest.mark.parametrize("dims,levels", [((75, 27, 256), (12, True, 4, True)), ((63, 33, 256), (10, True, 5, True)),
+                                         ((72, 24, 256), (12, False, 4, False)), ((63, 27, 128), (10, True, 4, True)),
+                                         ((63, 27, 512), (10, True, 4, True)), ((123, 63, 256), (20, True, 10, True))])
+def test_raw_entry_of_the_layered_family_equals_encode_then_forward(dims, levels):
+    """nerf_mlp_layered_forward(encoded = 0): raw points in, encodings written straight into the input planes
+    (encode_to_plane_kernel: one sincosf per (octave, channel)).  Bit for bit what PositionalEncoder.encode (posenc.hip:
+    sinf / cosf per element) followed by the pre-encoded entry computes -- outputs, parameter gradients and the
+    gradients w.r.t. the raw points -- in inference and record mode, ragged M, padded widths (72 -> 96, 123 -> 128)."""
+    lp, ip, ld, idr = levels
+    spec = ops.Net(dims[0], dims[1], dims[2], lp, ip, ld, idr)
+    assert not spec.fused
+    M = 3001
+    g = torch.Generator(device="cuda").manual_seed(3)
+    pts = (torch.rand((M, 3), device="cuda", generator=g) * 8 - 4).requires_grad_(True)
+    dirs = torch.nn.functional.normalize(torch.randn((M, 3), device="cuda", generator=g), dim=-1).requires_grad_(True)
+    gs, gc = torch.randn(M, device="cuda", generator=g), torch.randn((M, 3), device="cuda", generator=g)
+    net = network.NeRF(*dims).cuda()
+    enc = {"coord_enc": PositionalEncoder(3, lp, ip), "dir_enc": PositionalEncoder(3, ld, idr)}
+    cube = scene.PrimitiveCube(net, enc)
+    assert cube.raw_net().key == spec.key and cube.fused_net() is None
+    with torch.no_grad():
+        s_raw, c_raw = cube.query_points(pts.view(M, 1, 3), dirs.view(M, 1, 3))
+        s_enc, c_enc = net(enc["coord_enc"].encode(pts), enc["dir_enc"].encode(dirs))
+    assert torch.equal(s_raw.view(-1), s_enc) and torch.equal(c_raw.view(M, 3), c_enc)
+    grads = []
+    for raw in (True, False):
+        for t in (pts, dirs, *net.parameters()):
+            t.grad = None
+        if raw:
+            sigma, rgb = cube.query_points(pts.view(M, 1, 3), dirs.view(M, 1, 3))
+            sigma, rgb = sigma.view(-1), rgb.view(M, 3)
+        else:
+            sigma, rgb = net(enc["coord_enc"].encode(pts), enc["dir_enc"].encode(dirs))
+        assert torch.equal(sigma, s_enc) and torch.equal(rgb, c_enc)
+        ((sigma * gs).sum() + (rgb * gc).sum()).backward()
+        grads.append([t.grad.clone() for t in (pts, dirs, *net.parameters())])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)

@@ -170,9 +170,14 @@ def test_primitive_cube_contract():
     eno = {"coord_enc": PositionalEncoder(3, 10, False), "dir_enc": PositionalEncoder(3, 4, False)}
     assert scene.PrimitiveCube(network.NeRF(60, 24), eno).fused_net().key == (60, 24, 256, 10, 0, 4, 0)
     assert network.NeRF(60, 24).inferred_net().key == (60, 24, 256, 10, 0, 4, 0)
-    assert not scene.PrimitiveCube(network.NeRF(63, 27, 128), enc).fused_query          # layered family
+    # the layered family behind PositionalEncoders: no single-kernel render pass (fused_net), but query_points still hands
+    # RAW points to ONE network kernel -- the encodings go straight into its input planes (raw_net / fused_query)
+    narrow = scene.PrimitiveCube(network.NeRF(63, 27, 128), enc)
+    assert narrow.fused_net() is None and narrow.fused_query and narrow.raw_net().key == (63, 27, 128, 10, 1, 4, 1)
     e126 = {"coord_enc": PositionalEncoder(3, 12, True), "dir_enc": PositionalEncoder(3, 6, True)}
-    assert not scene.PrimitiveCube(network.NeRF(75, 39), e126).fused_query             # too wide for the fused kernels
+    wide = scene.PrimitiveCube(network.NeRF(75, 39), e126)                              # too wide for the fused kernels
+    assert wide.fused_net() is None and wide.raw_net().key == (75, 39, 256, 12, 1, 6, 1)
+    assert scene.PrimitiveCube(network.NeRF(75, 39), enc).raw_net() is None              # widths do not match the encoders
     with pytest.raises(ValueError):
         scene.PrimitiveCube("not a module", enc)
     with pytest.raises(ValueError):

@@ -336,6 +336,45 @@ __global__ __launch_bounds__(256) void rows_to_plane_kernel(const float *__restr
         }
     }
 }
+// plane[m][k] = PositionalEncoder(3, L, include_input).encode(x[m])[k] for k < E, 0 beyond / for the padded rows (TF layout):
+// the encoder kernel and rows_to_plane_kernel in one -- RAW points in, input plane out; the (M, E) row-major encoding
+// never exists.  One workgroup per 32-sample tile: the 32 x L x 3 (octave, channel) arguments get ONE sincosf each
+// (bit-identical to posenc.hip's sinf / cosf per element: scripts/sincos_probe.hip, 0 of 2^24 arguments over 16 octaves
+// differ), the tile's features are collected in LDS and leave as 16-byte units in memory order like rows_to_plane's.
+// Layout of a row (positional_encoder.py:83-88): [x y z (if include_input) | sin(2^0 xyz) cos(2^0 xyz) | sin(2^1 xyz) ...].
+constexpr int ENC_MAX_W = 256;
+__global__ __launch_bounds__(256) void encode_to_plane_kernel(const float *__restrict__ x, int64_t M, int64_t MP, int L, int inc,
+                                                              int E, int W, float *__restrict__ plane) {
+    __shared__ float t[32 * (ENC_MAX_W + 1)];
+    const int ld = W + 1, raw = inc ? 3 : 0;
+    for (int64_t tile = blockIdx.x; tile < MP / 32; tile += gridDim.x) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 32 * (W - E); idx += 256) {       // zero tail [E, W)
+            const int r = idx / (W - E), c = idx - r * (W - E);
+            t[r * ld + E + c] = 0.0f;
+        }
+        for (int idx = threadIdx.x; idx < 32 * 3 * (L + (inc ? 1 : 0)); idx += 256) {
+            const int r = idx % 32, j = idx / 32;          // j = 3 f' + c with f' = 0 the raw copy (if inc), then the octaves
+            const int c = j % 3, fq = j / 3;
+            const int64_t m = tile * 32 + r;
+            const float v = m < M ? x[3 * m + c] : 0.0f;
+            if (inc && fq == 0) { t[r * ld + c] = m < M ? v : 0.0f; continue; }
+            const int f = fq - (inc ? 1 : 0);
+            float sn, cs;
+            sincosf(ldexpf(v, f), &sn, &cs);               // 2^f * x, exact (:81, :87-88)
+            t[r * ld + raw + 6 * f + c] = m < M ? sn : 0.0f;
+            t[r * ld + raw + 6 * f + 3 + c] = m < M ? cs : 0.0f;
+        }
+        __syncthreads();
+        for (int u = threadIdx.x; u < W * 8; u += 256) {                     // 16-byte units: 64 per 256-float slot
+            const int slot = u >> 6, w = u & 63;
+            const int unit = w ^ (2 * (slot & 3));
+            const int r = unit >> 1, k = 32 * (slot >> 2) + 8 * (slot & 3) + 4 * (unit & 1);
+            const f32x4 v = {t[r * ld + k], t[r * ld + k + 1], t[r * ld + k + 2], t[r * ld + k + 3]};
+            *reinterpret_cast<f32x4 *>(plane + tile * 32 * W + (int64_t)slot * 256 + 4 * w) = v;
+        }
+    }
+}
 __global__ void plane_to_rows_kernel(const float *__restrict__ plane, int64_t M, int E, int W, float *__restrict__ rows) {
     const int64_t total = M * E;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -1392,8 +1431,8 @@ NERF_API int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t
 }
 
 NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params, const float *pos,
-                                      const float *view_dir, int64_t M, float *sigma, float *rgb, void *record,
-                                      int64_t record_rows, int keep_record, nerf_stream_t stream) {
+                                      const float *view_dir, int64_t M, int encoded, float *sigma, float *rgb,
+                                      void *record, int64_t record_rows, int keep_record, nerf_stream_t stream) {
     nerf_net_t d;
     if (nerf::net_describe(net, d) < 0) return NERF_ERR_ARG;
     NERF_REQUIRE(M >= 0, "nerf_mlp_layered_forward: negative M");
@@ -1404,6 +1443,12 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
     NERF_REQUIRE(!keep_record || record_rows >= M, "nerf_mlp_layered_forward: a kept record needs record_rows >= M");
     const bool recording = keep_record != 0;
     const Dims D = make_dims(d);
+    if (!encoded) {   // RAW (M, 3) points / directions: the two PositionalEncoders of nerf_net_t are applied on the way into the planes
+        if (d.pos_levels < 0 || d.dir_levels < 0)
+            return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_mlp_layered_forward: raw inputs need the levels of both PositionalEncoders "
+                                                    "in nerf_net_t (other encoders: encode first, pass encoded = 1)");
+        NERF_REQUIRE(D.Pp <= ENC_MAX_W && D.Dp <= ENC_MAX_W, "nerf_mlp_layered_forward: raw inputs: encodings wider than 256");
+    }
     hipStream_t s = nerf::as_stream(stream);
     int64_t chunk = record_rows < M ? record_rows : M;
     const Sizes z = sizes(D, chunk, false, 0);
@@ -1425,10 +1470,17 @@ NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params
     for (int64_t r0 = 0; r0 < M; r0 += chunk) {
         const int64_t rows = M - r0 < chunk ? M - r0 : chunk;
         const int64_t MP = lrows(rows);
-        hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * 8)), dim3(256), 0, s, pos + r0 * D.E_p, rows, MP,
-                           D.E_p, D.Pp, planes + (int64_t)D.r_pe() * MP);
-        hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * 8)), dim3(256), 0, s, view_dir + r0 * D.E_d, rows, MP,
-                           D.E_d, D.Dp, planes + (int64_t)D.r_de() * MP);
+        if (encoded) {
+            hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * 8)), dim3(256), 0, s, pos + r0 * D.E_p, rows, MP,
+                               D.E_p, D.Pp, planes + (int64_t)D.r_pe() * MP);
+            hipLaunchKernelGGL(rows_to_plane_kernel, dim3(grid_for(MP * 8)), dim3(256), 0, s, view_dir + r0 * D.E_d, rows, MP,
+                               D.E_d, D.Dp, planes + (int64_t)D.r_de() * MP);
+        } else {
+            hipLaunchKernelGGL(encode_to_plane_kernel, dim3(grid_for(MP * 8)), dim3(256), 0, s, pos + r0 * 3, rows, MP,
+                               d.pos_levels, d.pos_include_input ? 1 : 0, D.E_p, D.Pp, planes + (int64_t)D.r_pe() * MP);
+            hipLaunchKernelGGL(encode_to_plane_kernel, dim3(grid_for(MP * 8)), dim3(256), 0, s, view_dir + r0 * 3, rows, MP,
+                               d.dir_levels, d.dir_include_input ? 1 : 0, D.E_d, D.Dp, planes + (int64_t)D.r_de() * MP);
+        }
         if (int rc = nerf::check_launch("nerf_mlp_layered_forward: input planes")) return rc;
         WideArgs a = {};
         a.D = D; a.stream = reinterpret_cast<const char *>(fstream); a.consts = consts;

@@ -443,15 +443,17 @@ class NerfMLPFunction(torch.autograd.Function):
 LAYERED_INFERENCE_ROWS = 65536     # rows of activation scratch an inference call walks the batch with
 
 
-def mlp_layered_forward(flat_params, pos, view_dir, net: Net, record: bool = False):
-    """NeRF.forward on pre-encoded inputs through the layered family (csrc/mlp_layered.hip): ONE persistent launch
-    walks all eleven layers (register-resident for the widths reg_ok admits, plane-parked otherwise).
+def mlp_layered_forward(flat_params, pos, view_dir, net: Net, record: bool = False, encoded: bool = True):
+    """NeRF.forward through the layered family (csrc/mlp_layered.hip): ONE persistent launch walks all eleven layers
+    (register-resident for the widths reg_ok admits, plane-parked otherwise).
+    encoded=True: pos (M,pos_dim), view_dir (M,view_dir_dim) pre-encoded; encoded=False: RAW points / directions (M,3)
+    and `net` names both PositionalEncoders -- the encodings go straight into the kernel's input planes.
     record=True keeps the activation / ReLU-bit planes of all M rows for mlp_layered_backward; record=False is the
     inference call: only scratch for LAYERED_INFERENCE_ROWS rows, and no planes written at all on register-resident
     networks.  -> (sigma (M,), rgb (M,3)[, record tensor])."""
     lib = _lib.load()
     flat_params, pos, view_dir = _gpu(flat_params, "flat_params"), _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
-    _check_rows(pos, view_dir, True, net)
+    _check_rows(pos, view_dir, encoded, net)
     if flat_params.numel() != lib.nerf_mlp_param_count(net.ref):
         raise ValueError(f"expected {lib.nerf_mlp_param_count(net.ref)} parameters, got {flat_params.numel()}")
     M = pos.shape[0]
@@ -462,8 +464,9 @@ def mlp_layered_forward(flat_params, pos, view_dir, net: Net, record: bool = Fal
                       device=pos.device)
     with torch.cuda.device(pos.device):
         end = _timed("mlp_layered_forward", M)
-        _lib.check(lib.nerf_mlp_layered_forward(net.ref, _ptr(flat_params), _ptr(pos), _ptr(view_dir), M, _ptr(sigma),
-                                                _ptr(rgb), _ptr(rec), max(rows, 1), int(bool(record)), _stream()),
+        _lib.check(lib.nerf_mlp_layered_forward(net.ref, _ptr(flat_params), _ptr(pos), _ptr(view_dir), M,
+                                                int(bool(encoded)), _ptr(sigma), _ptr(rgb), _ptr(rec), max(rows, 1),
+                                                int(bool(record)), _stream()),
                    "nerf_mlp_layered_forward")
         if end is not None:
             end.record()
@@ -493,20 +496,22 @@ def mlp_layered_backward(flat_params, pos, view_dir, net: Net, sigma, rgb, rec, 
 
 
 class NerfLayeredFunction(torch.autograd.Function):
-    """sigma, rgb = NeRF(pos, view_dir) on pre-encoded inputs through the layered kernels; differentiable w.r.t. the
-    22 parameters AND the two inputs (what the reference's autograd provides, nerf.py:102-119).
-    apply(pos, view_dir, record, flat_params, net, *params)."""
+    """sigma, rgb = NeRF(pos, view_dir) through the layered kernels; differentiable w.r.t. the 22 parameters AND the two
+    inputs (what the reference's autograd provides, nerf.py:102-119; for RAW inputs the reverse of
+    PositionalEncoder.encode is chained behind the kernels' input gradients, like NerfMLPFunction).
+    apply(pos, view_dir, record, flat_params, net, encoded, *params)."""
 
     @staticmethod
-    def forward(ctx, pos, view_dir, record, flat_params, net, *params):
+    def forward(ctx, pos, view_dir, record, flat_params, net, encoded, *params):
         ctx.net = net
+        ctx.encoded = bool(encoded)
         ctx.shapes = [p.shape for p in params]
         pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
         if record:
-            sigma, rgb, rec = mlp_layered_forward(flat_params, pos, view_dir, net, record=True)
+            sigma, rgb, rec = mlp_layered_forward(flat_params, pos, view_dir, net, record=True, encoded=encoded)
             ctx.save_for_backward(pos, view_dir, flat_params, sigma, rgb, rec)
         else:
-            sigma, rgb = mlp_layered_forward(flat_params, pos, view_dir, net, record=False)
+            sigma, rgb = mlp_layered_forward(flat_params, pos, view_dir, net, record=False, encoded=encoded)
         return sigma, rgb
 
     @staticmethod
@@ -516,12 +521,25 @@ class NerfLayeredFunction(torch.autograd.Function):
             g_sigma = torch.zeros_like(sigma)
         if g_rgb is None:
             g_rgb = torch.zeros_like(rgb)
-        g_flat, g_pos, g_dir = mlp_layered_backward(flat_params, pos, view_dir, ctx.net, sigma, rgb, rec, g_sigma, g_rgb,
-                                                    want_pos=ctx.needs_input_grad[0], want_dir=ctx.needs_input_grad[1])
-        return (g_pos, g_dir, None, None, None, *_split_like(g_flat, ctx.shapes))
+        want_pos, want_dir = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        net = ctx.net
+        if ctx.encoded:
+            shaped_pos, shaped_dir = pos, view_dir
+        else:    # the kernels return gradients w.r.t. the ENCODED rows: (M, pos_dim) / (M, view_dir_dim) buffers
+            shaped_pos = pos.new_empty((pos.shape[0], net.pos_dim)) if want_pos else pos
+            shaped_dir = pos.new_empty((pos.shape[0], net.view_dir_dim)) if want_dir else view_dir
+        g_flat, g_pos, g_dir = mlp_layered_backward(flat_params, shaped_pos, shaped_dir, net, sigma, rgb, rec, g_sigma, g_rgb,
+                                                    want_pos=want_pos, want_dir=want_dir)
+        if not ctx.encoded:
+            key = net.key
+            if g_pos is not None:
+                g_pos = posenc_backward(pos, g_pos, key[3], bool(key[4]))
+            if g_dir is not None:
+                g_dir = posenc_backward(view_dir, g_dir, key[5], bool(key[6]))
+        return (g_pos, g_dir, None, None, None, None, *_split_like(g_flat, ctx.shapes))
 
 
-# --------------------------------------------------------------------------- draws for sharded jobs (row e)
+# --------------------------------------------------------------------------- counter RNG (shared with shard.py)
 def counter_uniform(key: int, first: int, count: int, device) -> torch.Tensor:
     """`count` fp32 uniforms u(key, first + i) on the GPU (csrc/draws.hip); key is the 64-bit stream key."""
     lib = _lib.load()

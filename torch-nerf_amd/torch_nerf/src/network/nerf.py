@@ -126,27 +126,31 @@ class NeRF(nn.Module):
             self.warn_bf16_ignored()
         if self._net.fused:    # (gradients w.r.t. the inputs come out of the same dX chain)
             return ops.NerfMLPFunction.apply(pos, view_dir, True, record or input_grads, packed, flat, self._net, *params)
-        return ops.NerfLayeredFunction.apply(pos, view_dir, record or input_grads, flat, self._net, *params)
+        return ops.NerfLayeredFunction.apply(pos, view_dir, record or input_grads, flat, self._net, True, *params)
 
-    def fused_net(self, coord_enc, dir_enc):
-        """The ops.Net of this network behind the two given encoders if the fused kernels can evaluate the encodings in
-        registers -- both are PositionalEncoder(3, L, include_input) producing exactly pos_dim / view_dir_dim
-        features and the network is in the fused family -- else None."""
+    def raw_net(self, coord_enc, dir_enc):
+        """The ops.Net of this network behind the two given encoders if a kernel can take RAW points and encode them itself
+        -- both are PositionalEncoder(3, L, include_input) producing exactly pos_dim / view_dir_dim features -- else None.
+        Fused family: the encodings are evaluated in registers; layered family: written straight into the kernel's
+        input planes (pos_dim, view_dir_dim <= 256)."""
         def level(e, width):
             if type(e).__name__ != "PositionalEncoder" or getattr(e, "in_dim", None) != 3 or \
                     getattr(e, "out_dim", None) != width:
                 return None
             return int(e.embed_level), bool(e.include_input)
-        if not self._net.fused:
-            return None
         lp, ld = level(coord_enc, self._pos_dim), level(dir_enc, self._view_dir_dim)
-        if lp is None or ld is None:
+        if lp is None or ld is None or (not self._net.fused and max(self._pos_dim, self._view_dir_dim) > 256):
             return None
         key = (lp, ld)
         if getattr(self, "_fused_net_key", None) != key:
             self._fused_net_key = key
             self._fused_net = ops.Net(self._pos_dim, self._view_dir_dim, self._feat_dim, lp[0], lp[1], ld[0], ld[1])
         return self._fused_net
+
+    def fused_net(self, coord_enc, dir_enc):
+        """raw_net restricted to the fused family (feat_dim 256, pos_dim <= 64, view_dir_dim <= 32): the networks whose
+        whole render pass is ONE kernel (VolumeRenderer._render_fused) -- else None."""
+        return self.raw_net(coord_enc, dir_enc) if self._net.fused else None
 
     def inferred_net(self):
         """fused_net for PositionalEncoders inferred from the widths alone (6 L + 3 with the input, 6 L without:
@@ -163,7 +167,8 @@ class NeRF(nn.Module):
         return self.fused_net(coord_enc, dir_enc) is not None
 
     def forward_fused(self, points: torch.Tensor, view_dirs: torch.Tensor, net=None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """points, view_dirs (M,3) RAW: positional encoding happens inside the kernel.  `net` = fused_net(encoders);
+        """points, view_dirs (M,3) RAW: positional encoding happens inside the kernel (fused family) or on the way into
+        its input planes (layered family).  `net` = raw_net(encoders);
         omitted: PositionalEncoders inferred from the two widths (inferred_net).  Differentiable w.r.t. the parameters
         and the raw inputs (the reference's autograd reaches both through cube.py:59-72)."""
         params, flat, packed = self._stream()
@@ -177,6 +182,8 @@ class NeRF(nn.Module):
             if net.bf16_ok:
                 return ops.mlp_forward_bf16(self._stream_bf16(), points, view_dirs, net)
             self.warn_bf16_ignored(net)
+        if not net.fused:     # layered family behind PositionalEncoders: raw points in, encodings straight into the planes
+            return ops.NerfLayeredFunction.apply(points, view_dirs, record, flat, net, False, *params)
         return ops.NerfMLPFunction.apply(points, view_dirs, False, record, packed, flat, net, *params)
 
     def warn_bf16_ignored(self, net=None):

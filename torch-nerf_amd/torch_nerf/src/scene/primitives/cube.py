@@ -1,10 +1,11 @@
 """Cubic scene primitive: (positions, view directions) -> (density, radiance).
 
 Interface of torch_nerf/src/scene/primitives/cube.py:12-81.  When the primitive wraps the
-HIP-backed NeRF with the two standard positional encoders, the reshape -> encode -> encode ->
-MLP -> reshape chain of the reference (:59-76) is ONE fused kernel: the encodings are built
-in registers and never written to memory.  Any other combination goes through the
-encoders' and the network's own (HIP-backed) entry points, step by step.
+HIP-backed NeRF with two positional encoders, the reshape -> encode -> encode -> MLP -> reshape chain of the
+reference (:59-76) hands RAW points to the network kernel: ONE fused kernel with the encodings built in registers
+(feat_dim 256, pos_dim <= 64, view_dir_dim <= 32), or the encodings written straight into the layered kernel's input
+planes (any other size).  Any other combination (SHEncoder, foreign encoders) goes through the encoders' and the
+network's own (HIP-backed) entry points, step by step.
 """
 from typing import Dict, Optional, Tuple
 
@@ -30,18 +31,28 @@ class PrimitiveCube(PrimitiveBase):
         pe, de = enc.get("coord_enc"), enc.get("dir_enc")
         return None if pe is None or de is None else net.fused_net(pe, de)
 
+    def raw_net(self):
+        """ops.Net when query_points can hand RAW points to a kernel that encodes them itself (HIP NeRF of either family
+        behind two PositionalEncoders of matching widths), else None."""
+        net, enc = self._radiance_field, self._encoders
+        if not hasattr(net, "raw_net") or not enc:
+            return None
+        pe, de = enc.get("coord_enc"), enc.get("dir_enc")
+        return None if pe is None or de is None else net.raw_net(pe, de)
+
     @property
     def fused_query(self) -> bool:
-        """True when query_points runs as the single fused encode+MLP kernel."""
-        return self.fused_net() is not None
+        """True when query_points hands RAW points to ONE network kernel (no encoding tensor, no per-layer activations in
+        HBM on the inference path): the renderer then ignores `num_ray_batch`, which exists to bound those."""
+        return self.raw_net() is not None
 
     def query_points(self, pos: torch.Tensor, view_dir: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """pos, view_dir (N,S,3) -> sigma (N,S), radiance (N,S,3)."""
         num_ray, num_sample = super().query_points(pos, view_dir)
         flat = num_ray * num_sample
-        fused = self.fused_net()
-        if fused is not None:   # (differentiable w.r.t. pos / view_dir as well)
-            sigma, radiance = self._radiance_field.forward_fused(pos.reshape(flat, -1), view_dir.reshape(flat, -1), fused)
+        raw = self.raw_net()
+        if raw is not None:   # raw points in, no encoding tensor in HBM (differentiable w.r.t. pos / view_dir as well)
+            sigma, radiance = self._radiance_field.forward_fused(pos.reshape(flat, -1), view_dir.reshape(flat, -1), raw)
         else:
             enc = self._encoders or {}
             p, d = pos.reshape(flat, -1), view_dir.reshape(flat, -1)
