@@ -91,6 +91,17 @@ def render_step(renderer, scene_c, scene_f, pix, device_index):
     return c_rgb, f_rgb
 
 
+def cpu_model():
+    """`model name` of the host CPU (what lscpu prints), for the cpu_baseline objects."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def host_cores():
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
     cores = os.cpu_count() or 1
@@ -245,7 +256,7 @@ def cpu_baseline(flats, focal, pose, device):
     t_probe, *_ = run(64)
     n1 = int(min(1024, max(64, 64 * (8.0 / max(t_probe, 1e-3))))) // 64 * 64
     secs1, *_ = run(n1)
-    one = {"value": n1 / secs1, "unit": "rays/s", "cores": 1, "kind": "port",
+    one = {"value": n1 / secs1, "unit": "rays/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
            "sample": f"{n1} of the 4096 rays of one batch, coarse 64 + fine 64+128, forward, eager PyTorch CPU port "
                      f"(oracle/torch_port.py), torch.set_num_threads(1) as runners/runner_utils.py:427 sets it, "
                      f"{secs1:.1f} s"}
@@ -273,7 +284,8 @@ def cpu_baseline(flats, focal, pose, device):
     err = (g_f.cpu() - f_rgb).abs().max().item()
     mse = torch.mean((g_f.cpu().double() - f_rgb.double()) ** 2).item()
     psnr = float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)
-    base = {"value": n / secs, "unit": "rays/s", "cores": cores, "kind": "port",
+    base = {"value": n / secs, "unit": "rays/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "cpus_visible": os.cpu_count(),
             "sample": f"{n} of the 4096 rays of one batch, coarse 64 + fine 64+128, forward, eager PyTorch CPU "
                       f"port of the reference path (oracle/torch_port.py), {cores} threads, {secs:.1f} s per pass"}
     quality = {"psnr_vs_cpu_port_db": (None if psnr == float("inf") else round(psnr, 2)),
