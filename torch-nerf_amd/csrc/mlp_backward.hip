@@ -881,6 +881,9 @@ struct ListRing {
     void mark(int slot, hipStream_t s) {
         std::lock_guard<std::mutex> lock(mu);
         used[slot] = hipEventRecord(done[slot], s) == hipSuccess;
+        // (an event that cannot be recorded on this stream -- created under another device -- must not leave the slot
+        // looking free while its copy is in flight: drain the stream instead)
+        if (!used[slot]) (void)hipStreamSynchronize(s);
     }
 };
 ListRing g_list_ring;

@@ -21,8 +21,8 @@ _G1 = -7046029254386353131   # 0x9E3779B97F4A7C15
 _G2 = -3372029247567499371   # 0xD1342543DE82EF95
 
 
-# rays per launch of render_frame's kernel chain (non-fused networks): 16 384 x 192 samples x (pos_dim + view_dir_dim + 12)
-# floats of points / directions / encodings stay under ~2 GB for the widest yaml-reachable encoders
+# rays per launch of render_frame's kernel chain (non-fused networks): 16 384 x 192 samples of points, directions, sigma,
+# radiance (and, for encoders without a raw-point entry such as SHEncoder, the row-major encodings) stay well under 1 GB
 CHAIN_RAYS_PER_LAUNCH = 16384
 
 
@@ -131,8 +131,9 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
     coarse_net / fine_net: NeRF modules, or PrimitiveCube scenes (network + encoders).  Networks of the fused family
     behind PositionalEncoders run ONE kernel per pass and launch; every other combination the scene can evaluate --
     coord_encode_level >= 11, dir_encode_level >= 5, signal_encoder: sh -- runs the kernel chain sampling ->
-    scene.query_points (encoder kernels + the layered network kernel) -> integral per launch, in smaller launches
-    (the encodings of a launch are materialised in HBM).  Same pixel ranges, same counter draws, same all-gather.
+    scene.query_points (raw points into the layered network kernel behind PositionalEncoders; encoder kernel + network
+    kernel otherwise) -> integral per launch, in smaller launches (a launch's points and directions live in HBM).
+    Same pixel ranges, same counter draws, same all-gather.
     single_rank=True: the calling rank renders the whole frame alone, no collective (the 1-GPU image a sharded
     image must equal bit for bit)."""
     from torch_nerf.amd import ops
