@@ -88,10 +88,12 @@ def test_layered_family_is_bit_reproducible(name, dims):
         sigma, rgb, rec = ops.mlp_layered_forward(fp, pe, de, spec, record=True)
         s_inf, c_inf = ops.mlp_layered_forward(fp, pe, de, spec)
         g, g_pos, g_dir = ops.mlp_layered_backward(fp, pe, de, spec, sigma, rgb, rec, gs, gc, want_pos=True, want_dir=True)
-        out = (sigma, rgb, rec, s_inf, c_inf, g, g_pos, g_dir)
+        # without input gradients (every training step) the 256-feature networks take the register-resident reverse chain
+        g_plain, _, _ = ops.mlp_layered_backward(fp, pe, de, spec, sigma, rgb, rec, gs, gc)
+        out = (sigma, rgb, rec, s_inf, c_inf, g, g_pos, g_dir, g_plain)
         if first is None:
             first = [t.clone() for t in out]
-            assert torch.equal(sigma, s_inf) and torch.equal(rgb, c_inf)
+            assert torch.equal(sigma, s_inf) and torch.equal(rgb, c_inf) and torch.equal(g, g_plain)
         else:
             for k, (x, y) in enumerate(zip(first, out)):
                 assert same_bits(x, y), f"{name}: output {k} differs in repetition {rep}"

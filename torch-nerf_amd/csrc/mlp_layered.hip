@@ -823,10 +823,13 @@ __device__ __forceinline__ void bias_init(f32x16 (*acc)[NFB], const float *bias,
 // STRIDE), two chunks per pair.  `w0` = the already acquired first pair, or null.  `before(c)` runs in front of chunk c
 // (a hook: the reverse chain re-reads dY5 between the dY0 and the dY5 blocks of g_pos).
 // FRESH: the accumulators start from zero (C = 0 in the first MFMAs).
-template <int NSB, int NFBC, int STRIDE, int KPCX, int N, bool FRESH, bool ACQ_FIRST, class Seq, class Before>
+// STORES > 0 (one sample block): 2 STORES plane stores of `st` ride between the MFMA groups of the first chunks of the first two
+// pairs (PlaneStore: the blocks stored are the B operands of this very run and stay untouched through it).
+template <int NSB, int NFBC, int STRIDE, int KPCX, int N, bool FRESH, bool ACQ_FIRST, int STORES = 0, class Seq, class Before>
 __device__ __forceinline__ void run_blocks(f32x16 *acc0, f32x16 *acc1, Seq seq, Before before, const char *w0, const char *lds,
-                                           Pipe &pipe, const int (&offq)[4]) {
+                                           Pipe &pipe, const int (&offq)[4], const PlaneStore *st = nullptr) {
     constexpr int CH = (N + KPCX - 1) / KPCX, LAST = N - (CH - 1) * KPCX;   // chunks; k-blocks of the last one
+    static_assert(STORES == 0 || (NSB == 1 && CH >= 3), "spread stores: one sample block, two pairs to carry them");
     const char *w = w0;       // (ACQ_FIRST: the first pair is acquired here; a template flag, not `w0 == nullptr`: no run-time
                               // branch may sit around an acquire, and LDS address 0 is a valid pointer)
     static_for<CH>([&](auto cc) {
@@ -836,7 +839,10 @@ __device__ __forceinline__ void run_blocks(f32x16 *acc0, f32x16 *acc1, Seq seq, 
         auto b = [&](int sb, int kb) -> const f32x16 & { return seq(sb, c * KPCX + kb); };
         const char *wc = w + (c % 2) * CHUNK_BYTES;
         constexpr int NKBX = c == CH - 1 ? LAST : KPCX;
-        if constexpr (c % 2 == 0) mma_slots2<NFBC, NKBX, STRIDE, 0, 16, (FRESH && c == 0), NSB>(acc0, acc1, b, wc, offq, &pipe);
+        if constexpr (c % 2 == 0 && STORES > 0 && c < 4)
+            mma_slots2<NFBC, NKBX, STRIDE, 0, 16, (FRESH && c == 0), NSB, STORES, 2 * STORES, 2 * STORES>(acc0, acc1, b, wc, offq, &pipe, st,
+                                                                                                     (c / 2) * STORES);
+        else if constexpr (c % 2 == 0) mma_slots2<NFBC, NKBX, STRIDE, 0, 16, (FRESH && c == 0), NSB>(acc0, acc1, b, wc, offq, &pipe);
         else mma_slots2<NFBC, NKBX, STRIDE, 0, 0, false, NSB>(acc0, acc1, b, wc, offq);
         if (c % 2 == 1 || c == CH - 1) pipe.issue_done();
     });
@@ -849,6 +855,18 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
     // fc_9's pass is packed with at least two accumulator blocks per k-block (pass_nfb)
     constexpr int HB = NFB / 2, KPC = 8 / NFB, S9 = HB < 2 ? 2 : HB, KPC9 = 8 / S9, FP = 32 * NFB, HP = 32 * HB, TILE = 128 * NSB;
     static_assert(NSB * NFB <= 8 && NFB >= 2, "register budget");
+    // The stores of a recorded plane stay at the layer seam.  Spread between the MFMA groups of the layer that multiplies the
+    // stored blocks (PlaneStore, as in the fused family's record forward and in reg_dx_kernel below) they cost the
+    // one-sample-block kernels 1.2 % instead of gaining: A/B on one box, NeRF(75,27,256) at 786 432 samples, record forward
+    // 7.20 / 7.24 ms spread vs 7.12 / 7.13 ms at the seam (NeRF(99,27,256): 7.48 vs 7.35) -- round 5, after the trunk layers
+    // were peeled (before that the spread variants also spilled 160..250 B); two sample blocks: 2.13 vs 2.10 ms for feat 128.
+    // -DX_REG_SPREAD_STORES rebuilds the spread variant.
+#ifdef X_REG_SPREAD_STORES
+    constexpr bool SPREAD = RECORD && NSB == 1 && NFB == 8;
+#else
+    constexpr bool SPREAD = false;
+#endif
+    constexpr int SPREAD_STORES = SPREAD ? 2 * NFB : 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -898,7 +916,11 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
         float sig[NSB];
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) sig[sb] = 0.0f;
-        for (int l = 1; l <= 8; ++l) {
+        // one trunk layer l = 1..8: ReLU of the previous layer's accumulators, record, bias, multiply.  SKIP (l == 5: the encoded
+        // position first) and DENSITY (l == 8) are compile-time: as run-time branches inside one loop body they cost the
+        // one-sample-block record kernels their register allocation once the stores ride between the MFMAs
+        auto trunk_layer = [&](int l, auto skip_tag, auto density_tag) {
+            constexpr bool SKIP = decltype(skip_tag)::value, DENSITY = decltype(density_tag)::value;
             const char *w = lds + pipe.acquire();
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb)
@@ -906,14 +928,12 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
                 for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) act[sb][fb][r] = relu1(acc[sb][fb][r]);
-            // (the stores stay at the seam here.  Spread over the MFMA groups like the fused family's (PlaneStore), the
-            // one-sample-block variants spill 160..250 B -- every asm store needs a four-register copy of its data while
-            // accumulators, activations and encodings are all live -- and the two-sample-block variants, which do not spill
-            // once the direction block is fetched late, gain nothing: A/B 2.13 vs 2.10 ms for feat 128.)
+            PlaneStore st;
+            if (SPREAD) st.open(plane(D.r_h(l - 1)), FP, m[0], h, act[0]);
             if (RECORD) {
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) {
-                    save_plane<NFB, true>(plane(D.r_h(l - 1)), FP, m[sb], h, act[sb]);
+                    if (!SPREAD) save_plane<NFB, true>(plane(D.r_h(l - 1)), FP, m[sb], h, act[sb]);
                     unsigned w[NFB / 2];          // [h(l-1) > 0] as bits, for the reverse chain
                     pack_mask_words<NFB>(act[sb], w);
                     unsigned *mp = mask_words_of(a.rec, D.r_mask(l - 1), MP, m[sb], h, NFB / 2, 0);
@@ -921,22 +941,26 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
                     for (int k = 0; k < NFB / 2; ++k) mp[k] = w[k];
                 }
             }
-            if (l == 8) {   // density row of fc_8
+            if (DENSITY) {   // density row of fc_8
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) sig[sb] = half_dot<NFB>(cb + D.c_w8row(), act[sb], h);
             }
             bias_init<NSB, NFB, NFB>(acc, cb + D.c_bias(l), h);
-            if (l == 5) {
+            if constexpr (SKIP) {
                 // (the encoded position comes back from its plane -- L2-hot -- instead of living in 16 NSB PB registers
                 // through fc_1..fc_4)
                 load_pe();
                 auto S5 = [&](int sb, int k) -> const f32x16 & { return k < PB ? pe[sb][k < PB ? k : 0] : act[sb][k >= PB ? k - PB : 0]; };
-                run_blocks<NSB, NFB, NFB, KPC, PB + NFB, false, false>(acc[0], acc[NSB - 1], S5, none, w, lds, pipe, offq);
+                run_blocks<NSB, NFB, NFB, KPC, PB + NFB, false, false, SPREAD_STORES>(acc[0], acc[NSB - 1], S5, none, w, lds, pipe, offq, &st);
             } else {
                 auto A = [&](int sb, int k) -> const f32x16 & { return act[sb][k]; };
-                run_blocks<NSB, NFB, NFB, KPC, NFB, false, false>(acc[0], acc[NSB - 1], A, none, w, lds, pipe, offq);
+                run_blocks<NSB, NFB, NFB, KPC, NFB, false, false, SPREAD_STORES>(acc[0], acc[NSB - 1], A, none, w, lds, pipe, offq, &st);
             }
-        }
+        };
+        for (int l = 1; l <= 4; ++l) trunk_layer(l, std::false_type(), std::false_type());
+        trunk_layer(5, std::true_type(), std::false_type());
+        for (int l = 6; l <= 7; ++l) trunk_layer(l, std::false_type(), std::false_type());
+        trunk_layer(8, std::false_type(), std::true_type());
         // ---- fc_9 on cat([x[:, 1:], view_dir]) (:116-118); fc_8 has no ReLU (:113)
         f32x16 a9[NSB][HB];
         {
@@ -945,7 +969,9 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
             for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) act[sb][fb] = acc[sb][fb];
-            if (RECORD) {
+            PlaneStore st;
+            if (SPREAD) st.open(plane(D.r_h(8)), FP, m[0], h, act[0]);
+            if (RECORD && !SPREAD) {
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) save_plane<NFB, true>(plane(D.r_h(8)), FP, m[sb], h, act[sb]);
             }
@@ -965,7 +991,7 @@ __global__ __launch_bounds__(256, 1) void reg_forward_kernel(const WideArgs a) {
                     }
                 }
             auto Cat9 = [&](int sb, int k) -> const f32x16 & { return k < NFB ? act[sb][k < NFB ? k : 0] : de[sb][k >= NFB ? k - NFB : 0]; };
-            run_blocks<NSB, HB, S9, KPC9, NFB + DB, false, false>(a9[0], a9[NSB - 1], Cat9, none, w, lds, pipe, offq);
+            run_blocks<NSB, HB, S9, KPC9, NFB + DB, false, false, SPREAD_STORES>(a9[0], a9[NSB - 1], Cat9, none, w, lds, pipe, offq, &st);
         }
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
@@ -1191,6 +1217,160 @@ __global__ __launch_bounds__(256, 1) void narrow_dx_kernel(const WideArgs a) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// The reverse chain of the 256-feature networks of this family (feat_dim 225..256: NSB = 1, NFB = 8) when the caller does
+// not ask for input gradients -- the training step of the yaml-reachable encoder settings (coord_encode_level 11..16,
+// dir_encode_level 5..10; round 5).  Same stream (dx_pass without the input stages: fc_9^T, fc_8^T .. fc_1^T, every pass
+// eight output blocks, one k-block per chunk), same planes, same dW path as the general chain; but dY(l) stays in
+// registers between layers (128 accumulator + 128 activation registers, the ReLU decisions as four mask words) and its
+// 32 plane stores leave between the MFMA groups of the layer that multiplies it (PlaneStore: 16 in the first chunk of
+// each of the layer's first two pairs), like the fused family's dX chain.  The pass program does not depend on pos_dim /
+// view_dir_dim without the input stages: one instantiation.
+__global__ __launch_bounds__(256, 1) void reg_dx_kernel(const WideArgs a) {
+    constexpr int NFB = 8, HB = 4, FP = 256, HP = 128;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    float *cb = reinterpret_cast<float *>(lds + RING_SLOTS * CHUNK_BYTES);
+    for (int e = tid; e < a.D.c_floats() / 4; e += 256)
+        reinterpret_cast<f32x4 *>(cb)[e] = reinterpret_cast<const f32x4 *>(a.consts)[e];
+    int offq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) offq[q] = chunk_slot_offset(i, 2 * q + h);
+    Pipe pipe;
+    pipe.src_wave = a.stream + wave * 8192;
+    pipe.lane_off = (unsigned)lane * 16u;
+    pipe.lds_wave = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 8192u;
+    pipe.issued = 0; pipe.issue_pos = 0; pipe.consumed = 0;
+    pipe.n_pairs = a.n_pairs; pipe.skip_mask = 0;
+    __syncthreads();
+    pipe.issue();
+    const Dims &D = a.D;
+    const int64_t MP = a.MP;
+    auto gplane = [&](int off) { return a.grad + (int64_t)off * MP; };
+
+    for (int64_t tile = blockIdx.x; tile < MP / 128; tile += gridDim.x) {
+        const int64_t m = tile * 128 + wave * 32 + i;
+        // ---- heads (nerf.py:115, :119) and dY9 = (W_out^T d y10) . [h9 > 0]
+        float dsig;
+        f32x16 d9[HB];
+        {
+            const bool valid = m < a.M;
+            const int64_t mc = valid ? m : a.M - 1;
+            float gy[3], yv[3], gv[3];      // (all loads first, from the clamped row)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { yv[ch] = a.rgb_in[3 * mc + ch]; gv[ch] = a.g_rgb[3 * mc + ch]; }
+            const float sg = a.sigma_in[mc], gsg = a.g_sigma[mc];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float t = gv[ch] * yv[ch] * (1.0f - yv[ch]);
+                gy[ch] = valid ? t : 0.0f;
+            }
+            dsig = (valid && sg > 0.0f) ? gsg : 0.0f;
+            if (h == 0) {
+                const f32x4 g4 = {gy[0], gy[1], gy[2], 0.0f};
+                *reinterpret_cast<f32x4 *>(gplane(D.g_gy()) + 4 * m) = g4;
+                gplane(D.g_dsig())[m] = dsig;
+            }
+            unsigned b9[HB / 2];      // [h9 > 0]
+#pragma unroll
+            for (int k = 0; k < HB / 2; ++k) b9[k] = mask_words_of(a.rec, D.r_mask(8), MP, m, h, NFB / 2, 0)[k];
+#pragma unroll
+            for (int fb = 0; fb < HB; ++fb) {
+                f32x16 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k0 = 32 * fb + 8 * q + 4 * h;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + k0);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + HP + k0);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4 *>(cb + D.c_wout() + 2 * HP + k0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[4 * q + j] = fmaf(w2[j], gy[2], fmaf(w1[j], gy[1], w0[j] * gy[0]));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d9[fb][r] = keep_bit(b9[fb >> 1], 16 * (fb & 1) + r, v[r]);
+            }
+            save_plane<HB, true>(gplane(D.g_dy9()), HP, m, h, d9);
+        }
+        f32x16 acc[NFB], act[NFB];
+        unsigned mk[NFB / 2];        // the ReLU decisions of the next seam, from the record's bit planes
+        // ---- d y8[1:] = W9[:, :F]^T dY9: four k-blocks, one per chunk
+        {
+            const char *w = nullptr;
+            auto D9 = [&](int, int kb) -> const f32x16 & { return d9[kb]; };
+            static_for<HB>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if (c % 2 == 0) w = lds + pipe.acquire();
+                auto b = [&](int sb, int) -> const f32x16 & { return D9(sb, c); };
+                if constexpr (c % 2 == 0) mma_slots2<NFB, 1, NFB, 0, 16, c == 0, 1>(acc, acc, b, w, offq, &pipe);
+                else mma_slots2<NFB, 1, NFB, 0, 0, false, 1>(acc, acc, b, w + CHUNK_BYTES, offq);
+                if (c % 2 == 1) pipe.issue_done();
+            });
+        }
+        auto load_masks = [&](int l) {
+#pragma unroll
+            for (int k = 0; k < NFB / 2; ++k) mk[k] = mask_words_of(a.rec, D.r_mask(l), MP, m, h, NFB / 2, 0)[k];
+        };
+        auto apply_masks = [&]() {
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[fb][r] = keep_bit(mk[fb >> 1], 16 * (fb & 1) + r, acc[fb][r]);
+        };
+        // one layer of the chain: dY(l) = `act` is stored while it multiplies W_l^T; FRESH: the accumulators start from zero
+        auto layer = [&](int l, auto fresh_tag) {
+            constexpr bool FRESH = decltype(fresh_tag)::value;
+            PlaneStore st;            // dY(l) leaves between the MFMA groups of the first chunks of the first two pairs
+            st.open(gplane(D.g_dy(l)), FP, m, h, act);
+            const char *w = nullptr;
+            static_for<NFB>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if (c % 2 == 0) w = lds + pipe.acquire();
+                auto b = [&](int, int) -> const f32x16 & { return act[c]; };
+                if constexpr (c == 0) mma_slots2<NFB, 1, NFB, 0, 16, FRESH, 1, 16, 32, 32>(acc, acc, b, w, offq, &pipe, &st, 0);
+                else if constexpr (c == 2) mma_slots2<NFB, 1, NFB, 0, 16, false, 1, 16, 32, 32>(acc, acc, b, w, offq, &pipe, &st, 16);
+                else if constexpr (c % 2 == 0) mma_slots2<NFB, 1, NFB, 0, 16, false, 1>(acc, acc, b, w, offq, &pipe);
+                else mma_slots2<NFB, 1, NFB, 0, 0, false, 1>(acc, acc, b, w + CHUNK_BYTES, offq);
+                if (c % 2 == 1) pipe.issue_done();
+            });
+        };
+        // ---- l = 8: dY7' = W8[1:]^T d y8 + W8[0, :] dsigma' (the density row); fc_8 has no ReLU: d y8 is the accumulators as they are
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) act[fb] = acc[fb];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(cb + D.c_w8row() + 32 * fb + 8 * q + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[fb][4 * q + j] = wv[j] * dsig;
+            }
+        load_masks(7);
+        layer(8, std::false_type());
+        // ---- l = 7 .. 1: dY(l-1)' = W_l^T dY(l), dY(l) = dY(l)' . [h(l) > 0]
+        for (int l = 7; l >= 1; --l) {
+            apply_masks();
+            load_masks(l - 1);        // masks of the next seam, fetched one stage ahead
+            layer(l, std::true_type());
+        }
+        // ---- dY0
+        apply_masks();
+        save_plane<NFB, true>(gplane(D.g_dy(0)), FP, m, h, act);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int launch_reg_dx(const WideArgs &a, hipStream_t s) {
+    static nerf::DeviceMask configured{0};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(reg_dx_kernel), REG_LDS, configured,
+                                          "nerf_mlp_layered: LDS attribute (register-resident reverse chain)"))
+        return rc;
+    const int64_t ntiles = a.MP / 128;
+    const int cus = nerf::device_cus();
+    hipLaunchKernelGGL(reg_dx_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(256), REG_LDS, s, a);
+    return nerf::check_launch("nerf_mlp_layered_backward: reverse chain (register-resident, 256 features)");
 }
 
 template <int NSB, int NFB, int PB, int DB = 1>
@@ -1534,7 +1714,10 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
     a.rec = rec; a.grad = grad; a.M = M; a.MP = MP;
     a.n_passes = dx_num_passes(D, inputs); a.n_pairs = pa.n_pairs; a.inputs = inputs;
     a.sigma_in = sigma; a.rgb_in = rgb; a.g_sigma = g_sigma; a.g_rgb = g_rgb;
-    if (int rc = (reg_ok(D) && D.Fp <= 128) ? launch_narrow_dx(inputs != 0, a, s) : launch_program(true, a, s)) return rc;
+    // feat_dim <= 128: the narrow chains; feat_dim 225..256 without input gradients (every training step): the
+    // register-resident chain; everything else the general plane-parked chain
+    if (int rc = (reg_ok(D) && D.Fp <= 128) ? launch_narrow_dx(inputs != 0, a, s)
+                 : (reg_ok(D) && D.Fp == 256 && !inputs) ? launch_reg_dx(a, s) : launch_program(true, a, s)) return rc;
     if (g_pos) hipLaunchKernelGGL(plane_to_rows_kernel, dim3(grid_for(M * D.E_p)), dim3(256), 0, s,
                                   grad + (int64_t)D.g_gp() * MP, M, D.E_p, D.Pp, g_pos);
     if (g_view_dir) hipLaunchKernelGGL(plane_to_rows_kernel, dim3(grid_for(M * D.E_d)), dim3(256), 0, s,
