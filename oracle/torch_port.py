@@ -82,21 +82,22 @@ def rays(pix, height, width, focal, pose):
     return torch.zeros_like(cam) + pose[:3, -1], cam @ pose[:3, :3].t()
 
 
-def render_pass(p, o, d, near, far, n_coarse, u1, weights=None, u2=None, u3=None):
-    """One render_scene call (R/renderer/volume_renderer.py:136-169), single ray batch."""
+def render_pass(p, o, d, near, far, n_coarse, u1, weights=None, u2=None, u3=None, levels=(10, 4)):
+    """One render_scene call (R/renderer/volume_renderer.py:136-169), single ray batch.  `levels` = (coord_encode_level,
+    dir_encode_level) of the two PositionalEncoders (shipped yaml: 10 / 4)."""
     pts, dirs, delta, idx = sample(o, d, near, far, n_coarse, u1, weights, u2, u3)
     n, s, _ = pts.shape
-    sigma, rgb = mlp(p, encode(pts.reshape(n * s, 3), 10), encode(dirs.reshape(n * s, 3), 4))
+    sigma, rgb = mlp(p, encode(pts.reshape(n * s, 3), levels[0]), encode(dirs.reshape(n * s, 3), levels[1]))
     pix, w = integrate(sigma.reshape(n, s), rgb.reshape(n, s, 3), delta)
     # the reference returns torch.cat over its ray batches (volume_renderer.py:256-259): a NEW tensor, which is
     # why the fine pass may then do `weights += 1e-5` in place without invalidating the coarse graph
     return torch.cat([pix], 0), torch.cat([w], 0), idx
 
 
-def render_batch(p_coarse, p_fine, pix, height, width, focal, pose, near, far, n_coarse, n_fine, draws):
+def render_batch(p_coarse, p_fine, pix, height, width, focal, pose, near, far, n_coarse, n_fine, draws, levels=(10, 4)):
     """Coarse + fine pass for one pixel batch, as runners/train.py:172-201 issues them."""
     u1c, u1, u2, u3 = draws
     o, d = rays(pix, height, width, focal, pose)
-    c_rgb, c_w, _ = render_pass(p_coarse, o, d, near, far, n_coarse, u1c)
-    f_rgb, f_w, idx = render_pass(p_fine, o, d, near, far, n_coarse, u1, c_w, u2, u3)
+    c_rgb, c_w, _ = render_pass(p_coarse, o, d, near, far, n_coarse, u1c, levels=levels)
+    f_rgb, f_w, idx = render_pass(p_fine, o, d, near, far, n_coarse, u1, c_w, u2, u3, levels=levels)
     return c_rgb, c_w, f_rgb, f_w, idx

@@ -633,20 +633,30 @@ def param_digest(prefix, now, start):
     return d
 
 
-def f14_train_loop():
+def f14_train_loop(name="f14_train_loop", levels=(10, 4)):
     """The body of runners/train.py:120-218, statement for statement, for 20 consecutive iterations on the reference's
     classes: new camera, coarse render_scene, MSE, fine render_scene on the coarse pass's (floored in place) weights,
     MSE, backward, Adam.step, ExponentialLR.step -- optimizer and scheduler built as runner_utils.py:691-711 builds
     them (num_iter shortened to 40 so that the decay shows within 20 steps).  What only shows ACROSS steps -- the
     optimizer's moments and step counts, parameters that changed under a cached weight image, the learning-rate
     schedule, the in-place weight floor feeding the next call -- is pinned by the per-step losses, the pixels of three
-    iterations and digests of both networks' parameters after the last one."""
+    iterations and digests of both networks' parameters after the last one.
+    `levels` = (coord_encode_level, dir_encode_level) of configs/signal_encoder/positional_encoding.yaml:2-3: the shipped
+    (10, 4) and, as f14_train_loop_l12_l5, (12, 5) -- NeRF(75, 33), which the build serves with other kernels (layered
+    family: raw-point entry, register-resident forward with three position / two direction blocks, reg_dx_kernel)."""
     cfg = F14
     n, steps = cfg["n"], cfg["steps"]
-    flat_c = synth.nerf_flat_params(seed=3, sigma_bias=1.0, sigma_gain=30.0)
-    flat_f = synth.nerf_flat_params(seed=4, sigma_bias=1.0, sigma_gain=30.0)
-    enc = {"coord_enc": RefPE(3, 10, True), "dir_enc": RefPE(3, 4, True)}
-    net_c, net_f = load_ref_net(flat_c), load_ref_net(flat_f)
+    enc = {"coord_enc": RefPE(3, levels[0], True), "dir_enc": RefPE(3, levels[1], True)}
+    e_p, e_d = enc["coord_enc"].out_dim, enc["dir_enc"].out_dim
+    flat_c = synth.nerf_flat_params(seed=3, pos_dim=e_p, view_dir_dim=e_d, sigma_bias=1.0, sigma_gain=30.0)
+    flat_f = synth.nerf_flat_params(seed=4, pos_dim=e_p, view_dir_dim=e_d, sigma_bias=1.0, sigma_gain=30.0)
+
+    def load(flat):
+        net = ref_nerf.NeRF(e_p, e_d)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.split_flat_params(flat, e_p, e_d, 256).items()})
+        return net
+
+    net_c, net_f = load(flat_c), load(flat_f)
     default_scene, fine_scene = ref_scene.PrimitiveCube(net_c, enc), ref_scene.PrimitiveCube(net_f, enc)
     sampler = ref_samplers.StratifiedSampler()
     renderer = ref_vr.VolumeRenderer(ref_integrators.QuadratureIntegrator(), sampler,
@@ -695,12 +705,17 @@ def f14_train_loop():
         out.update(param_digest(tag, now, flat))
     out["config"] = np.array([n, steps, cfg["init_lr"], cfg["end_lr"], cfg["num_iter"], cfg["eps"]], np.float64)
     out["keep"] = np.array(cfg["keep"], np.int64)
-    save("f14_train_loop", **out)
+    out["levels"] = np.array(levels, np.int64)
+    save(name, **out)
+
+
+def f14_train_loop_l12_l5():
+    f14_train_loop("f14_train_loop_l12_l5", (12, 5))
 
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    every = dict(f14=f14_train_loop, f13=f13_instant_ngp, f12=f12_sh_encoder, f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
+    every = dict(f14=f14_train_loop, f14b=f14_train_loop_l12_l5, f13=f13_instant_ngp, f12=f12_sh_encoder, f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
                  f8=f8_adam)
     for name in (sys.argv[1:] or list(every)):      # e.g. `make_golden.py f8` rewrites one fixture
         every[name]()

@@ -124,7 +124,7 @@ def f14_inputs(step, n=96):
     return pose, pix, gt, draws
 
 
-def param_digest_error(now, start, g, prefix):
+def param_digest_error(now, start, g, prefix):  # (any network size: the digest indexes the flat vector)
     """Worst deviations of a parameter vector from the digest F14 stores (make_golden.py:param_digest), as
     {tag}_abs = max |v - ref|, {tag}_rel_rms = the same over rms(ref), {tag}_p99_rel_rms = its 99th percentile over rms(ref),
     {tag}_norm_rel = |‖v‖ - ‖ref‖| / ‖ref‖ for tag in (p, dp = p - start); the digest holds 192 leading + 1536 strided values."""

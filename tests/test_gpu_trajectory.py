@@ -58,18 +58,20 @@ class _Replay:
         return d
 
 
-def _make_net(flat):
-    net = network.NeRF(63, 27)
-    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.split_flat_params(flat).items()})
+def _make_net(flat, e_p=63, e_d=27):
+    net = network.NeRF(e_p, e_d)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.split_flat_params(flat, e_p, e_d, 256).items()})
     return net.cuda()
 
 
 def run_loop(g, optimizer_kind, monkeypatch):
     n, steps, init_lr, end_lr, num_iter, eps = g["config"]
     n, steps = int(n), int(steps)
-    flats = [synth.nerf_flat_params(seed=s, sigma_bias=1.0, sigma_gain=30.0) for s in (3, 4)]
-    enc = {"coord_enc": PositionalEncoder(3, 10, True), "dir_enc": PositionalEncoder(3, 4, True)}
-    net_c, net_f = _make_net(flats[0]), _make_net(flats[1])
+    levels = tuple(int(v) for v in g["levels"])
+    enc = {"coord_enc": PositionalEncoder(3, levels[0], True), "dir_enc": PositionalEncoder(3, levels[1], True)}
+    e_p, e_d = enc["coord_enc"].out_dim, enc["dir_enc"].out_dim
+    flats = [synth.nerf_flat_params(seed=s, pos_dim=e_p, view_dir_dim=e_d, sigma_bias=1.0, sigma_gain=30.0) for s in (3, 4)]
+    net_c, net_f = _make_net(flats[0], e_p, e_d), _make_net(flats[1], e_p, e_d)
     default_scene, fine_scene = scene.PrimitiveCube(net_c, enc), scene.PrimitiveCube(net_f, enc)
     focal = float(synth.blender_focal(800))
 
@@ -125,14 +127,18 @@ def run_loop(g, optimizer_kind, monkeypatch):
     return drift
 
 
+@pytest.mark.parametrize("fixture", ["f14_train_loop", "f14_train_loop_l12_l5"])
 @pytest.mark.parametrize("optimizer_kind", ["torch", "fused"])
-def test_training_loop_follows_the_reference(golden, monkeypatch, optimizer_kind):
-    g = golden("f14_train_loop")
+def test_training_loop_follows_the_reference(golden, monkeypatch, optimizer_kind, fixture):
+    """f14_train_loop: the shipped encoders (fused family: single-kernel query, record forward / dX / dW kernels);
+    f14_train_loop_l12_l5: coord_encode_level 12, dir_encode_level 5 -- NeRF(75, 33) on the layered family (raw-point
+    entry, register-resident forward with three position / two direction blocks, reg_dx_kernel, dW list kernel)."""
+    g = golden(fixture)
     drift = run_loop(g, optimizer_kind, monkeypatch)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
-        json.dump(drift, open(os.path.join(out, f"f14_drift_{optimizer_kind}.json"), "w"), indent=1)
-    print("F14 drift", optimizer_kind, json.dumps(drift))
+        json.dump(drift, open(os.path.join(out, f"{fixture}_drift_{optimizer_kind}.json"), "w"), indent=1)
+    print("F14 drift", fixture, optimizer_kind, json.dumps(drift))
     assert drift["loss"] < LOSS_ATOL and drift["pixel"] < PIXEL_ATOL, (drift["loss"], drift["pixel"])
     beyond = [i for i, row in enumerate(drift["per_step"])
               if max(abs(row["coarse_loss"]), abs(row["fine_loss"])) > LOSS_TYPICAL]

@@ -1,5 +1,6 @@
 """The eager-torch CPU port (bench.py's cpu_baseline) against the reference's golden vectors."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import torch_port as TP
@@ -26,18 +27,22 @@ def test_port_reproduces_reference_end_to_end(golden):
     np.testing.assert_allclose(f_w.numpy(), g["fine_w"], rtol=0, atol=1e-5)
 
 
-def test_port_reproduces_reference_training_loop(golden):
+@pytest.mark.parametrize("fixture", ["f14_train_loop", "f14_train_loop_l12_l5"])
+def test_port_reproduces_reference_training_loop(golden, fixture):
     """Golden F14: 20 iterations of runners/train.py:120-218 on the imported reference.  The port runs the same ATen
     ops in the same order under torch's own autograd and Adam, so the whole trajectory -- per-step losses, pixels,
     the parameters after the last step -- must come out to rounding; this also checks that tests/helpers.py
     regenerates the fixture's inputs."""
     from helpers import f14_inputs, param_digest_error
-    g = golden("f14_train_loop")
+    g = golden(fixture)
     n, steps, init_lr, end_lr, num_iter, eps = g["config"]
     n, steps = int(n), int(steps)
+    levels = tuple(int(v) for v in g["levels"])
+    e_p, e_d = 6 * levels[0] + 3, 6 * levels[1] + 3
     torch.set_num_threads(8)
-    flats = [synth.nerf_flat_params(seed=s, sigma_bias=1.0, sigma_gain=30.0) for s in (3, 4)]
-    nets = [{k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in synth.split_flat_params(f).items()} for f in flats]
+    flats = [synth.nerf_flat_params(seed=s, pos_dim=e_p, view_dir_dim=e_d, sigma_bias=1.0, sigma_gain=30.0) for s in (3, 4)]
+    nets = [{k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in synth.split_flat_params(f, e_p, e_d, 256).items()}
+            for f in flats]
     params = [p for net in nets for p in net.values()]
     optimizer = torch.optim.Adam(params, lr=init_lr, eps=eps)
     scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, pow(end_lr / init_lr, 1 / num_iter))
@@ -49,7 +54,7 @@ def test_port_reproduces_reference_training_loop(golden):
         assert abs(optimizer.param_groups[0]["lr"] - g["lr"][step]) < 1e-12
         c_rgb, _, f_rgb, _, _ = TP.render_batch(nets[0], nets[1], torch.from_numpy(pix), 800, 800, focal,
                                                 torch.from_numpy(pose), 2.0, 6.0, 64, 128,
-                                                tuple(torch.from_numpy(d) for d in draws))
+                                                tuple(torch.from_numpy(d) for d in draws), levels=levels)
         c_loss, f_loss = mse(torch.from_numpy(gt), c_rgb), mse(torch.from_numpy(gt), f_rgb)
         assert abs(c_loss.item() - g["coarse_loss"][step]) < 2e-6 and abs(f_loss.item() - g["fine_loss"][step]) < 2e-6, step
         if step in g["keep"]:
