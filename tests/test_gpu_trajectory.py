@@ -10,9 +10,9 @@ last step, under torch.optim.Adam AND FusedAdam.
 
 Bounds.  Adam makes parameter trajectories chaotic in the elements whose gradient is rounding noise (update = lr * m /
 (sqrt(v) + eps), sign-like for tiny gradients): the imported reference run with 1 or 4 threads instead of the fixture's
-8 -- another sgemm summation order, nothing else -- already moves the losses by 3e-7, the norm of the 20-step update by
-1e-4 relative, its 99th-percentile element by 0.09 and single elements by up to 0.6 of the update's rms (DESIGN.md
-section 2).  The bounds below are 3x the worst the GPU path measured (gpurun_out/f14_drift_*.json on the run that set
+8 -- another sgemm summation order, nothing else -- already moves the losses by 3e-7, the pixels of iteration 20 by
+9.5e-5, the norm of the 20-step update by 1e-4 relative, its 99th-percentile element by 0.09 and single elements by up
+to 0.6 of the update's rms (tests/golden/f14_self_drift.py).  The bounds below are 3x the worst the GPU path measured (gpurun_out/f14_drift_*.json on the run that set
 them), and are of the same size as that self-drift."""
 import json
 import os
