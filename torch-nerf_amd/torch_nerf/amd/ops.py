@@ -481,8 +481,9 @@ def mlp_layered_backward(flat_params, pos, view_dir, net: Net, sigma, rgb, rec, 
     g_sigma, g_rgb = _gpu(g_sigma, "g_sigma"), _gpu(g_rgb, "g_rgb")
     dev = pos.device
     g_params = torch.empty((lib.nerf_mlp_param_count(net.ref),), dtype=torch.float32, device=dev)
-    g_pos = torch.empty_like(pos) if want_pos else None
-    g_dir = torch.empty_like(view_dir) if want_dir else None
+    # (gradients w.r.t. the ENCODED rows, whatever `pos` / `view_dir` are -- raw (M, 3) points when the forward took those)
+    g_pos = torch.empty((M, net.pos_dim), dtype=torch.float32, device=dev) if want_pos else None
+    g_dir = torch.empty((M, net.view_dir_dim), dtype=torch.float32, device=dev) if want_dir else None
     ws = torch.empty((max(lib.nerf_mlp_layered_workspace_bytes(net.ref, M), 4) // 4,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         end = _timed("mlp_layered_backward", M)
@@ -523,14 +524,9 @@ class NerfLayeredFunction(torch.autograd.Function):
             g_rgb = torch.zeros_like(rgb)
         want_pos, want_dir = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         net = ctx.net
-        if ctx.encoded:
-            shaped_pos, shaped_dir = pos, view_dir
-        else:    # the kernels return gradients w.r.t. the ENCODED rows: (M, pos_dim) / (M, view_dir_dim) buffers
-            shaped_pos = pos.new_empty((pos.shape[0], net.pos_dim)) if want_pos else pos
-            shaped_dir = pos.new_empty((pos.shape[0], net.view_dir_dim)) if want_dir else view_dir
-        g_flat, g_pos, g_dir = mlp_layered_backward(flat_params, shaped_pos, shaped_dir, net, sigma, rgb, rec, g_sigma, g_rgb,
+        g_flat, g_pos, g_dir = mlp_layered_backward(flat_params, pos, view_dir, net, sigma, rgb, rec, g_sigma, g_rgb,
                                                     want_pos=want_pos, want_dir=want_dir)
-        if not ctx.encoded:
+        if not ctx.encoded:    # the kernels returned gradients w.r.t. the encoded rows: back through the encoders
             key = net.key
             if g_pos is not None:
                 g_pos = posenc_backward(pos, g_pos, key[3], bool(key[4]))
