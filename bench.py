@@ -1153,6 +1153,15 @@ def main():
         result["configs"] = guarded("configs", lambda: configs_leg(nets, flats, device))
     if rank == 0 and world == 1 and not args.no_configs:
         result["encoders"] = guarded("encoders", lambda: encoder_variants_leg(device, local_rank, max(5, args.steps // 4), 2))
+        if isinstance(result.get("configs"), dict) and "error" not in result["encoders"]:
+            # the same three whole-pass figures beside the other BASELINE configurations (VERDICT r04 item 4 asked for them
+            # there); the full objects -- training step, frame -- stay under `encoders`
+            for tag, setting in (("coord_l12", "coord_encode_level: 12"), ("dir_l5", "dir_encode_level: 5"), ("sh", "signal_encoder: sh")):
+                e = result["encoders"][tag]
+                result["configs"]["enc_" + tag] = {"ms": e["ms_per_step"], "rays_per_s": e["rays_per_s"], "rays": RAYS,
+                                                   "mlp_frac": e["mlp_frac"], "network": e["network"],
+                                                   "what": f"{setting}: 4096 rays x (64+128), coarse + fine render_scene, whole "
+                                                           "pass (sampling + encode + network + integral), fp32"}
     if world == 1 and not args.no_bf16:
         result["bf16"] = guarded("bf16", lambda: bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank,
                                                           args.steps, 3))
