@@ -215,3 +215,52 @@ def test_sampler_draws_follow_the_reference_order():
     c1, c2, c3 = s.draw_uniforms(5, 64, 0, "cpu")
     assert torch.equal(c1, want[0]) and c2 is None and c3 is None
     assert s.check_sample_counts(64, None) == (64, 0) and s.check_sample_counts((64, 128), torch.ones(1, 64)) == (64, 128)
+
+
+def test_nerf_parameters_share_one_blob_without_changing_the_module_surface():
+    """NeRF._rehome (round 6): the 22 parameters are views of one flat storage from the constructor on (the kernels read
+    them in place, so writes through p.data can never go stale) -- invisible through the nn.Module surface the
+    runners use: state_dict keys / shapes / values, load_state_dict, deepcopy, optimizer steps, torch.save round trip."""
+    import copy
+    import io
+    torch.manual_seed(0)
+    net = network.NeRF(63, 27)
+    params = net._ordered_params()
+    store = params[0].untyped_storage().data_ptr()
+    off = params[0].data_ptr()
+    for p in params:
+        assert p.untyped_storage().data_ptr() == store and p.data_ptr() == off and p.is_contiguous() and p.is_leaf
+        off += 4 * p.numel()
+    # default nn.Linear initialisation survives the move (same generator draws as eleven nn.Linear in a row)
+    torch.manual_seed(0)
+    ref = [torch.nn.Linear(i, o) for o, i in synth.layer_shapes()]
+    for (name, p), q in zip(net.named_parameters(), [t for l in ref for t in (l.weight, l.bias)]):
+        assert torch.equal(p, q), name
+    # load_state_dict copies INTO the blob; an alias taken before stays an alias
+    alias = net.fc_4.weight.data
+    expect = synth.split_flat_params(synth.nerf_flat_params(seed=2))
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in expect.items()})
+    assert net._ordered_params()[0].untyped_storage().data_ptr() == store
+    assert np.array_equal(alias.numpy(), expect["fc_4.weight"])
+    # deepcopy: an independent module with its own blob
+    twin = copy.deepcopy(net)
+    twin.fc_1.bias.data.add_(1.0)
+    assert not torch.equal(twin.fc_1.bias, net.fc_1.bias)
+    assert twin._ordered_params()[0].untyped_storage().data_ptr() != store
+    # a stock optimizer steps the views in place
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    for p in net.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert np.allclose(net.fc_4.weight.detach().numpy(), expect["fc_4.weight"] - 1e-3, atol=1e-6)
+    assert np.array_equal(alias.numpy(), net.fc_4.weight.detach().numpy())
+    # torch.save / load round trip of the state_dict (runner_utils.py:758-775)
+    buf = io.BytesIO()
+    torch.save(net.state_dict(), buf)
+    buf.seek(0)
+    back = torch.load(buf)
+    assert list(back) == list(expect) and all(torch.equal(back[k], net.state_dict()[k]) for k in back)
+    # .double() / .float(): still one blob afterwards
+    net = net.double().float()
+    params = net._ordered_params()
+    assert all(p.untyped_storage().data_ptr() == params[0].untyped_storage().data_ptr() for p in params)

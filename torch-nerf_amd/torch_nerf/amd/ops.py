@@ -265,8 +265,19 @@ def mlp_param_count(net: Optional[Net] = None) -> int:
     return int(_lib.load().nerf_mlp_param_count(_ref(net)))
 
 
-def mlp_pack(flat_params: torch.Tensor, net: Optional[Net] = None) -> torch.Tensor:
-    """Flat state_dict blob (fp32, GPU) -> packed LDS-image stream of the fused kernels (uint8 GPU tensor)."""
+def _pack_buffer(out, nbytes, device, what):
+    """`out` if it is a stream buffer of the right size on the right device (re-packed in place, stream-ordered behind
+    whatever still reads it), else a fresh one."""
+    if out is None:
+        return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    if out.dtype != torch.uint8 or out.numel() != nbytes or out.device != device or not out.is_contiguous():
+        raise ValueError(f"{what}: `out` is not a {nbytes}-byte uint8 buffer on {device}")
+    return out
+
+
+def mlp_pack(flat_params: torch.Tensor, net: Optional[Net] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Flat state_dict blob (fp32, GPU) -> packed LDS-image stream of the fused kernels (uint8 GPU tensor; `out`: an
+    earlier stream of the same network, overwritten in place)."""
     lib = _lib.load()
     flat_params = _gpu(flat_params, "flat_params")
     if flat_params.numel() != lib.nerf_mlp_param_count(_ref(net)):
@@ -274,7 +285,7 @@ def mlp_pack(flat_params: torch.Tensor, net: Optional[Net] = None) -> torch.Tens
     nbytes = lib.nerf_mlp_packed_bytes(_ref(net))
     if nbytes < 0:
         raise RuntimeError(f"mlp_pack: {lib.nerf_amd_last_error().decode()}")
-    packed = torch.empty((nbytes,), dtype=torch.uint8, device=flat_params.device)
+    packed = _pack_buffer(out, nbytes, flat_params.device, "mlp_pack")
     with torch.cuda.device(flat_params.device):
         _lib.check(lib.nerf_mlp_pack(_ref(net), _ptr(flat_params), _ptr(packed), _stream()), "nerf_mlp_pack")
     return packed
@@ -327,13 +338,13 @@ def mlp_forward(packed: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor,
     return (sigma, rgb, saved) if save else (sigma, rgb)
 
 
-def mlp_pack_bf16(flat_params: torch.Tensor, net: Optional[Net] = None) -> torch.Tensor:
-    """Flat fp32 state_dict blob -> bf16 fragment stream for mlp_forward_bf16 (uint8 GPU tensor)."""
+def mlp_pack_bf16(flat_params: torch.Tensor, net: Optional[Net] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Flat fp32 state_dict blob -> bf16 fragment stream for mlp_forward_bf16 (uint8 GPU tensor; `out` as in mlp_pack)."""
     lib = _lib.load()
     flat_params = _gpu(flat_params, "flat_params")
     if flat_params.numel() != lib.nerf_mlp_param_count(_ref(net)):
         raise ValueError(f"expected {lib.nerf_mlp_param_count(_ref(net))} parameters, got {flat_params.numel()}")
-    packed = torch.empty((lib.nerf_mlp_packed_bf16_bytes(_ref(net)),), dtype=torch.uint8, device=flat_params.device)
+    packed = _pack_buffer(out, lib.nerf_mlp_packed_bf16_bytes(_ref(net)), flat_params.device, "mlp_pack_bf16")
     with torch.cuda.device(flat_params.device):
         _lib.check(lib.nerf_mlp_pack_bf16(_ref(net), _ptr(flat_params), _ptr(packed), _stream()), "nerf_mlp_pack_bf16")
     return packed

@@ -47,6 +47,8 @@ class NeRF(nn.Module):
         # BASELINE configs[2]: set to True to evaluate no-grad fused queries with bf16 weights and
         # bf16 layer inputs on the bf16 MFMA path (fp32 accumulate).  Training always runs in fp32.
         self.bf16_inference = False
+        self._flat_is_view = False
+        self._rehome()
 
     # ------------------------------------------------------------------ parameters -> kernel stream
     def _ordered_params(self):
@@ -61,28 +63,60 @@ class NeRF(nn.Module):
             out.append(params["bias"])
         return out
 
-    def _stream(self):
-        """(parameters, flat blob, packed LDS-image stream | None for the layered family), rebuilt only when a
-        parameter changed."""
+    def _rehome(self):
+        """Make the 22 parameters views of ONE flat blob, in state_dict order, so that the kernels read the live values in
+        place (no per-call concatenation, nothing to go stale).  Done where the parameters get their storage -- the
+        constructor and every .to() / .cuda() / .float() (nn.Module._apply) -- and never later: an alias of `p.data`
+        taken by the caller after that point (EMA helpers, hand-written optimizers) stays an alias of the parameter."""
         params = self._ordered_params()
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        first = params[0]
+        if any(p.dtype != first.dtype or p.device != first.device for p in params) or first.device.type == "meta":
+            return
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in params])
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._rehome()
+        return out
+
+    def _stream(self):
+        """(parameters, flat blob, packed LDS-image stream | None for the layered family) of the parameter values AS THEY
+        ARE NOW.  The reference's eager module reads its parameters at call time (nerf.py:102-119), so an in-place write
+        through `p.data` (EMA, manual weight decay, old-style optimizers) -- which moves neither data_ptr() nor
+        `_version` -- must be seen by the next call: the flat blob is a VIEW of the parameters (see _rehome) and the LDS
+        image is re-packed from it on every call (one 8-us kernel in front of a 2-8 ms launch); only the host-side
+        bookkeeping -- where the parameters live -- is cached."""
+        params = self._ordered_params()
+        key = tuple(p.data_ptr() for p in params)
         if key != self._pack_key:
             if not params[0].is_cuda:
                 raise RuntimeError("NeRF parameters must be on the GPU: the HIP path has no CPU fallback")
+            self._flat_is_view = False
             with torch.no_grad():
                 self._flat = self._blob_view(params)
-                if self._flat is None:
-                    self._flat = torch.cat([p.detach().reshape(-1) for p in params]).float().contiguous()
-                self._packed = ops.mlp_pack(self._flat, self._net) if self._net.fused else None
-                self._packed_bf16 = None
+                self._flat_is_view = self._flat is not None
             self._pack_key = key
+        with torch.no_grad():
+            if not self._flat_is_view:
+                # somebody re-assigned single parameters (p.data = ...): they no longer sit back to back.  Their new
+                # tensors may be aliased by the caller, so they are left where they are and concatenated per call
+                self._flat = torch.cat([p.detach().reshape(-1) for p in params]).float().contiguous()
+            if self._net.fused:
+                self._packed = ops.mlp_pack(self._flat, self._net, out=self._packed)
         return params, self._flat, self._packed
 
     def _stream_bf16(self):
-        """The bf16 fragment stream of the current parameters (BASELINE configs[2]), packed on first use."""
+        """The bf16 fragment stream of the current parameter values (BASELINE configs[2]), re-packed per call like
+        _stream's."""
         _, flat, _ = self._stream()
-        if self._packed_bf16 is None:
-            self._packed_bf16 = ops.mlp_pack_bf16(flat, self._net)
+        with torch.no_grad():
+            self._packed_bf16 = ops.mlp_pack_bf16(flat, self._net, out=self._packed_bf16)
         return self._packed_bf16
 
     @staticmethod
