@@ -234,6 +234,63 @@ def bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank, steps, warmup):
             "what": "render step with bf16 weights + bf16 layer inputs (v_mfma_f32_32x32x16_bf16, fp32 accumulate)"}
 
 
+def f16x2_leg(renderer, scene_c, scene_f, nets, pix, local_rank, steps, warmup):
+    """Secondary figure (round 6): the same render step with the MLP on the f16 matrix pipe, every operand split in two
+    f16 parts (three v_mfma_f32_16x16x32_f16 per k-step, fp32 accumulate): the fp32 BOUND -- 1e-5 abs, tests/
+    test_gpu_f16x2.py -- at a multiple of the fp32 MFMA kernel's speed.  The headline stays the fp32-MFMA kernel:
+    BASELINE configs[1] names fp32.  roofline: 3x the algorithmic MLP FLOPs (the three part products the kernel
+    issues) against the dense f16 MFMA peak; `equivalent_fp32_TFLOPs` = the algorithmic FLOPs alone."""
+    from torch_nerf.amd import ops
+
+    def run(s, seed):
+        torch.manual_seed(seed)
+        return render_step(renderer, scene_c, scene_f, pix[s], local_rank)
+
+    with torch.no_grad():
+        ref_c, ref = run(0, 99)
+        for net in nets:
+            net.f16x2_inference = True
+        got_c, got = run(0, 99)
+        for s in range(warmup):
+            run(s, s)
+        torch.cuda.synchronize()
+        rounds = []
+        for rnd in range(3):
+            ops.KERNEL_EVENTS = []
+            t0 = time.perf_counter()
+            for s in range(warmup, warmup + steps):
+                render_step(renderer, scene_c, scene_f, pix[s % len(pix)], local_rank)
+            torch.cuda.synchronize()
+            rounds.append((time.perf_counter() - t0, ops.KERNEL_EVENTS))
+        ops.KERNEL_EVENTS = None
+        dt, events = sorted(rounds, key=lambda r: r[0])[1]
+        for net in nets:
+            net.f16x2_inference = False
+    durs = [(M, e0.elapsed_time(e1)) for tag, M, e0, e1 in events if tag == "mlp_forward_f16x2"]
+    total_ms = sum(ms for _, ms in durs)
+    algorithmic = sum(M for M, _ in durs) * MLP_FLOP_PER_SAMPLE / (total_ms * 1e-3) / 1e12
+    achieved = 3.0 * algorithmic
+    fine = [ms for M, ms in durs if M == RAYS * (N_COARSE + N_FINE)]
+    err = (got - ref).abs().max(dim=1).values
+    roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": ops.DOMINANT_KERNEL_F16X2 + ", 2 launches/step", "launches": len(durs),
+                "ms_per_launch": round(total_ms / len(durs), 4),
+                "fine_ms_per_launch": round(float(np.mean(fine)), 4) if fine else None,
+                "equivalent_fp32_TFLOPs": round(algorithmic, 1),
+                "vs_fp32_mfma_peak": round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 3)}
+    return {"rays_per_s": RAYS * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f16x2",
+            "ms_per_step_rounds": [round(r[0] / steps * 1e3, 4) for r in rounds],
+            "coarse_max_abs_err_vs_fp32": (got_c - ref_c).abs().max().item(),
+            "fine_median_abs_err_vs_fp32": err.median().item(),
+            "fine_pixels_beyond_1e-5": int((err > 1e-5).sum().item()),
+            "fine_max_abs_err_vs_fp32": err.max().item(), "roofline": roofline,
+            "what": "render step with every MLP operand split in two f16 parts (lo.hi + hi.lo + hi.hi on "
+                    "v_mfma_f32_16x16x32_f16, fp32 accumulate): the fp32 1e-5 bound on the f16 matrix pipe; fine pixels "
+                    "beyond 1e-5 of the fp32 step are rays where a 1e-7 change of a coarse weight moved a fine sample "
+                    "across a cdf boundary (the coarse pass has no such step: its bound is the kernel's)"}
+
+
 def cpu_baseline(flats, focal, pose, device):
     """Eager-torch CPU port on the host cores; returns the JSON objects (all cores, 1 thread) + PSNR of HIP vs port."""
     from oracle import torch_port as TP
@@ -921,6 +978,7 @@ def main():
     ap.add_argument("--fault-rank", type=int, default=-1, help="test hook: this rank exits (code 17) right after the "
                     "rendezvous, before the first data collective -- the others must fail within --dist-timeout, not hang")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-MFMA render measurement")
+    ap.add_argument("--no-f16x2", action="store_true", help="skip the secondary split-f16 (fp32-grade on the f16 matrix pipe) render measurement")
     ap.add_argument("--no-frame", action="store_true", help="skip the 800x800 sharded full-frame leg")
     ap.add_argument("--no-stages", action="store_true", help="skip the HBM-bound stage measurements")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes that measure HBM "
@@ -1165,6 +1223,9 @@ def main():
     if world == 1 and not args.no_bf16:
         result["bf16"] = guarded("bf16", lambda: bf16_leg(renderer, scene_c, scene_f, nets, pix, local_rank,
                                                           args.steps, 3))
+    if world == 1 and not args.no_f16x2:
+        result["f16x2"] = guarded("f16x2", lambda: f16x2_leg(renderer, scene_c, scene_f, nets, pix, local_rank,
+                                                             args.steps, 3))
     if not args.no_train:       # world > 1: data-parallel (one gradient all-reduce per step inside FusedAdam)
         result["train"] = guarded("train", lambda: train_leg(renderer, scene_c, scene_f, nets, pix, device,
                                                              local_rank, max(3, args.steps // 4), 2, world))

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 4
+#define NERF_AMD_ABI_VERSION 5
 
 enum {
     NERF_OK = 0,
@@ -136,6 +136,18 @@ int64_t nerf_mlp_packed_bf16_bytes(const nerf_net_t *net);
 int nerf_mlp_pack_bf16(const nerf_net_t *net, const float *params, void *packed_bf16, nerf_stream_t stream);
 int nerf_mlp_forward_bf16(const nerf_net_t *net, const void *packed_bf16, const float *pos, const float *view_dir, int64_t M,
                           float *sigma, float *rgb, nerf_stream_t stream);
+
+/* ---- a10, split-f16 variant ("f16x2", ABI v5): NeRF.forward (R/network/nerf.py:102-119) at the fp32 bound -- 1e-5 abs on
+ * sigma / rgb, like nerf_mlp_forward -- on the f16 matrix pipe.  Every operand of the ten matrix-pipe layers is split
+ * in two f16 parts (weights at pack time, scaled per layer by a power of two; activations in the layer seams) and
+ * every k-step forms lo.hi + hi.lo + hi.hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation; encodings, biases,
+ * the density row, fc_out and the sigmoid stay fp32.  pos, view_dir are RAW (M,3); inference only; the fused family
+ * behind two PositionalEncoders.  Activations beyond +-65504 overflow to inf / NaN (never a silent wrong value).
+ * Same `params` blob as nerf_mlp_pack. */
+int64_t nerf_mlp_packed_f16x2_bytes(const nerf_net_t *net);
+int nerf_mlp_pack_f16x2(const nerf_net_t *net, const float *params, void *packed_f16x2, nerf_stream_t stream);
+int nerf_mlp_forward_f16x2(const nerf_net_t *net, const void *packed_f16x2, const float *pos, const float *view_dir, int64_t M,
+                           float *sigma, float *rgb, nerf_stream_t stream);
 
 /* ---- a13 (MLP part): gradients of all 22 parameter tensors (autograd in the
  * reference, entered at runners/train.py:215).  g_params (param_count floats, same

@@ -21,7 +21,7 @@ def test_library_builds_loads_and_exports_header():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nerf_amd_abi_version() == 4
+    assert lib.nerf_amd_abi_version() == 5
     assert lib.nerf_mlp_param_count(None) == 595844
     # sizes only -- no compute without a GPU
     assert lib.nerf_mlp_packed_bytes(None) == 13312 + (78 + 74) * 32768   # 68 transposed chunks + 3 input-gradient pairs
@@ -125,6 +125,12 @@ def test_entry_points_refuse_what_they_cannot_serve_before_touching_the_gpu():
     assert lib.nerf_mlp_forward_bf16(f128, p, p, p, 4, p, p, None) == UNSUPPORTED   # bf16: the fused family only
     other = net(39, 15, 256, 6, 1, 2, 1)
     assert lib.nerf_mlp_packed_bf16_bytes(other) > 0                                # run-time levels: served since round 4
+    # split-f16 variant (ABI v5): the fused family behind PositionalEncoders, mixed include_input allowed
+    assert lib.nerf_mlp_forward_f16x2(sh, p, p, p, 4, p, p, None) == UNSUPPORTED and b"levels" in lib.nerf_amd_last_error()
+    assert lib.nerf_mlp_forward_f16x2(f128, p, p, p, 4, p, p, None) == UNSUPPORTED
+    assert lib.nerf_mlp_packed_f16x2_bytes(f128) == -1 and lib.nerf_mlp_packed_f16x2_bytes(other) == 13312 + 73 * 32768
+    assert lib.nerf_mlp_pack_f16x2(None, None, None, None) == ARG
+    assert lib.nerf_mlp_forward_f16x2(None, p, p, p, 0, p, p, None) == OK and lib.nerf_mlp_forward_f16x2(None, p, p, p, -1, p, p, None) == ARG
     bad = net(63, 27, 256, 9, 1, 4, 1)
     assert lib.nerf_mlp_forward(bad, p, p, p, 4, 1, p, p, None, None) == ARG
     assert lib.nerf_mlp_layered_forward(bad, p, p, p, 4, 1, p, p, p, 4, 0, None) == ARG

@@ -1,0 +1,377 @@
+// fp32-grade inference on the f16 matrix pipe: the fused encode + MLP kernel with every operand SPLIT in two f16 parts.
+//
+// Why: the fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the vector rate -- 157 TFLOP/s, 1/16 of the f16 / bf16 matrix
+// pipe -- and the fp32 kernels sit at 0.94 of that peak.  An fp32 value is hi + lo with hi = f16(x), lo = f16(x - hi)
+// to 22 significand bits (subnormal low parts are kept by the pipe: scripts/f16_split_probe.hip), the part products
+// are exact in the pipe's fp32 accumulation, and lo.hi + hi.lo + hi.hi reproduces an fp32 dot product to the fp32
+// kernel's own error class (K = 256: 1.0 - 2.5e-7 of sum |a b| against 1.1 - 1.3e-7 for the fp32 MFMA chain,
+// profiles/r06_f16_split_probe.txt).  Three products at 16x the rate: the bound of north_star (1e-5 abs on sigma, rgb,
+// pixels) is met with the margin of the fp32 kernels (scripts/split_emulate.py on goldens F5 / F7 / F11: <= 9e-7), which
+// bf16 parts cannot do in three products (1e-5: two bf16 parts carry 16 bits).
+//
+// Same algebra as mlp_forward_bf16.hip -- Y^T = W X^T, the D fragment of one layer is the B fragment of the next -- with:
+//   * v_mfma_f32_16x16x32_f16, SIXTEEN samples per wavefront: a layer's state per lane is 64 accumulators + 32 + 32
+//     registers of packed hi / lo activations, so that two wavefronts per SIMD fit (256 registers each) and one wave's
+//     seam (scale, ReLU, split, bias) runs under its SIMD partner's MFMAs.  (32 samples per wave would need 128 + 64 +
+//     64 = 256 registers before the first temporary.)
+//   * workgroup = 8 wavefronts = 128 samples per pass; weights scaled per layer by a power of two, split at pack time
+//     (mlp_pack.hip), streamed in 32-KiB sub-steps [hi image | lo image] of one 32-wide k-block through the bf16 kernel's
+//     4-slot LDS ring, the two halves of the workgroup one sub-step apart; 73 sub-steps per tile.  An A fragment is
+//     one ds_read_b128; the hi fragment feeds two MFMAs, the lo fragment one: 2 KiB of LDS reads per 3 MFMAs
+//   * encodings in fp32 (one accurate sincos per needed feature, the library path for huge arguments, like the fp32
+//     kernels), split like every other activation; biases ride pre-scaled in the C fragment; the density row of fc_8
+//     (from the unsplit fp32 h7), fc_out and the sigmoid stay fp32 on the vector ALU
+// Every network of the fused family behind two PositionalEncoders (run-time levels / include_input).  Inference only.
+// Range: activations beyond +-65504 overflow the hi part (-> inf / NaN in the outputs, never a silent wrong value).
+#include <type_traits>
+
+#include "mlp_device.h"
+#include "net.h"
+
+namespace {
+
+using namespace mlp;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVES = 8;
+constexpr int WSAMPLES = 16;                     // samples per wavefront (the N of 16x16x32)
+constexpr int TILE = WSAMPLES * WAVES;           // samples per workgroup pass
+constexpr int SUB_BYTES = F2_SUB_BYTES;
+constexpr int RING = 4;
+constexpr int SUBS_PER_TILE = F2_SUBS;
+constexpr int PIECES = SUB_BYTES / 1024 / WAVES; // 1-KiB DMA pieces per wave per sub-step
+constexpr int F2_LDS_BYTES = RING * SUB_BYTES + CONST_BYTES;
+static_assert(PIECES == 4, "ring geometry");
+
+// (the bf16 kernel's pipe: see mlp_forward_bf16.hip for the slot / barrier protocol)
+struct SubPipe {
+    const char *src_wave;  // stream base + wave * 4 KiB (wave-uniform)
+    unsigned lane_off;     // lane * 16
+    unsigned lds_wave;     // LDS address of ring slot 0 + wave * 4 KiB
+    unsigned issued;       // sub-steps requested so far (ring slot = issued % RING)
+    int issue_q;           // position in the tile, [0, SUBS_PER_TILE), of the next sub-step to request
+    unsigned consumed;     // sub-steps this wave has consumed
+
+    __device__ __forceinline__ void issue_piece(int p) const {
+        lds_dma_16s(src_wave + issue_q * SUB_BYTES + p * 1024, lane_off,
+                    lds_wave + (issued & (RING - 1)) * SUB_BYTES + p * 1024);
+    }
+    __device__ __forceinline__ void issue_done() {
+        ++issued;
+        issue_q = (issue_q + 1 == SUBS_PER_TILE) ? 0 : issue_q + 1;
+    }
+    __device__ __forceinline__ void rendezvous() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PIECES) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ unsigned acquire() {
+        rendezvous();
+        const unsigned off = (consumed & (RING - 1)) * SUB_BYTES;
+        ++consumed;
+        return off;
+    }
+    __device__ __forceinline__ void idle_step() {
+        rendezvous();
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) issue_piece(p);
+        issue_done();
+    }
+};
+
+__device__ __forceinline__ f16x8 lds_read_fragment16(unsigned lds_addr, int imm_offset) {
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(imm_offset));
+    return v;
+}
+
+// acc[fb] += W'[16 fb .. 16 fb + 15][this 32-wide k-block] . x  for fb < NFB, W' = hi + lo and x = bhi + blo:
+//   acc += lo.bhi ; acc += hi.blo ; acc += hi.bhi      (small terms first)
+// `addr` = LDS address of the k-block's hi image + this lane's fragment offset; the lo image sits LO_OFF bytes behind.
+// Output blocks go two at a time (six MFMAs, the dependent ones three apart), their four A fragments read two pairs ahead
+// in three rotating buffer sets; N_PIECES > 0: DMA pieces 0 .. N_PIECES-1 of the next sub-step ride between the pairs.
+template <int NFB, int N_PIECES, int HI_OFF, int LO_OFF>
+__device__ __forceinline__ void mma_kblock(f32x4 (&acc)[16], const f16x8 &bhi, const f16x8 &blo, unsigned addr,
+                                           const SubPipe &pipe) {
+    constexpr int PAIRS = NFB / 2, AHEAD = 2, EVERY = N_PIECES > 0 ? PAIRS / N_PIECES : 1;
+    static_assert(NFB % 2 == 0 && (N_PIECES == 0 || PAIRS % N_PIECES == 0), "pairs of output blocks; pieces divide them");
+    f16x8 ah[3][2], al[3][2];
+    auto fetch = [&](int p) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ah[p % 3][j] = lds_read_fragment16(addr, HI_OFF + (2 * p + j) * 1024);
+            al[p % 3][j] = lds_read_fragment16(addr, LO_OFF + (2 * p + j) * 1024);
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < AHEAD && p < PAIRS; ++p) fetch(p);
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+        // pairs p+1 .. p+AHEAD-1 may still be in flight: four reads each
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + 1 < PAIRS) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + AHEAD < PAIRS) fetch(p + AHEAD);
+        const int b = p % 3, f0 = 2 * p, f1 = 2 * p + 1;
+        acc[f0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b][0], bhi, acc[f0], 0, 0, 0);
+        acc[f1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b][1], bhi, acc[f1], 0, 0, 0);
+        acc[f0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b][0], blo, acc[f0], 0, 0, 0);
+        acc[f1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b][1], blo, acc[f1], 0, 0, 0);
+        if (N_PIECES > 0 && p % EVERY == 0) pipe.issue_piece(p / EVERY);
+        acc[f0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b][0], bhi, acc[f0], 0, 0, 0);
+        acc[f1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b][1], bhi, acc[f1], 0, 0, 0);
+    }
+}
+
+// x (fp32, four features of one output block) -> elements 4 half .. 4 half + 3 of the hi / lo B fragments
+__device__ __forceinline__ void split4(const f32x4 &x, f16x8 &hi, f16x8 &lo, int half) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const _Float16 h = (_Float16)x[r];
+        hi[4 * half + r] = h;
+        lo[4 * half + r] = (_Float16)(x[r] - (float)h);      // exact difference (compiled with -ffp-contract=off)
+    }
+}
+
+// B fragments (hi, lo) of NKB 32-wide k-blocks of PositionalEncoder(3, levels, include_input).encode((x, y, z)) for lane
+// group g: element e of block kb is feature 32 kb + 16 (e>>2) + 4 g + (e&3) (positional_encoder.py:83-88), zero from
+// `width` = out_dim on
+template <int NKB, bool EXACT>
+__device__ __forceinline__ void encode_split(float x, float y, float z, int g, int width, int include_input,
+                                             f16x8 (&hi)[NKB], f16x8 (&lo)[NKB]) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = enc_feature<EXACT>(32 * kb + 16 * half + 4 * g + r, x, y, z, width, include_input);
+            split4(v, hi[kb], lo[kb], half);
+        }
+}
+
+__global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const Net net, const char *__restrict__ packed,
+                                                                           const float *__restrict__ pos,
+                                                                           const float *__restrict__ dir, int64_t M,
+                                                                           float *__restrict__ sigma_out,
+                                                                           float *__restrict__ rgb_out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool trailing = wave >= WAVES / 2;   // this half runs one sub-step behind the other
+    const int n = lane & 15, g = lane >> 4;    // sample of the wave's 16, lane group (rows 4 g .. 4 g + 3 of every D block)
+    float *cb_ = reinterpret_cast<float *>(lds);
+    const unsigned ring = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)CONST_BYTES;
+    for (int e = tid; e < CONST_FLOATS / 4; e += 64 * WAVES)
+        reinterpret_cast<f32x4 *>(cb_)[e] = reinterpret_cast<const f32x4 *>(packed)[e];
+
+    // A fragment of output block fb, lane (row n of the block, lane group g): row 16 fb + n, logical slot g
+    const unsigned frag = ring + (unsigned)b16_frag_offset(n, g);
+
+    SubPipe pipe;
+    pipe.src_wave = packed + CONST_BYTES + wave * (PIECES * 1024);
+    pipe.lane_off = (unsigned)lane * 16u;
+    pipe.lds_wave = ring + (unsigned)wave * (PIECES * 1024u);
+    pipe.issued = 0;
+    pipe.issue_q = 0;
+    pipe.consumed = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // sub-steps 0 and 1 are in flight before the first rendezvous
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) pipe.issue_piece(p);
+        pipe.issue_done();
+    }
+    if (trailing) pipe.idle_step();
+
+    const int64_t ntiles = (M + TILE - 1) / TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t m = tile * TILE + wave * WSAMPLES + n;
+        const bool valid = m < M;
+        const int64_t mc = valid ? m : M - 1;
+        float raw[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            raw[c] = pos[3 * mc + c];
+            raw[3 + c] = dir[3 * mc + c];
+        }
+        // (wave-uniform: one sample with a huge argument sends the wave down the library path)
+        const bool exact = __any(encoding_needs_exact(raw, net.l_pos, net.l_dir));
+
+        f32x4 acc[16];                 // [16-feature output block]
+        f16x8 act_hi[8], act_lo[8];    // [32-feature input block]
+        f16x8 pe_hi[2], pe_lo[2];      // the encoded position: fc_in and the fc_5 skip connection
+        f16x8 de_hi[1], de_lo[1];      // the encoded direction (fc_9): evaluated up front too, while nothing else is live
+        float sigma_pre = 0.0f;
+        // (the lane group as a value hipcc cannot reason about: the feature-index arithmetic of the encodings would
+        // otherwise be hoisted out of the tile loop and held in ~50 registers across the whole MFMA stream)
+        int ge = g;
+        asm volatile("" : "+v"(ge));
+
+        // one sub-step of a 256-row layer: one k-block against all 16 output blocks
+        auto sub_step = [&](const f16x8 &bhi, const f16x8 &blo) {
+            const unsigned a = frag + pipe.acquire();
+            mma_kblock<16, PIECES, 0, F2_IMAGE_BYTES>(acc, bhi, blo, a, pipe);
+            pipe.issue_done();
+        };
+        // accumulators <- the (pre-scaled) bias of the next layer, blocks [FIRST, FIRST + COUNT)
+        auto load_bias_blocks = [&](const float *bias, int first, int count) {
+#pragma unroll
+            for (int fb = 0; fb < 16; ++fb)
+                if (fb >= first && fb < first + count) acc[fb] = *reinterpret_cast<const f32x4 *>(bias + 16 * fb + 4 * g);
+        };
+        // Layer seam, one HALF (output blocks 8 HALF_IX .. 8 HALF_IX + 7) per call: accumulators of the finished layer l ->
+        // its activation (x 2^-s_l, ReLU) -> packed hi / lo inputs of the next layer; the accumulator block restarts from
+        // the next layer's bias.  As in the bf16 kernel the first half runs BEFORE the rendezvous of the next layer's
+        // first sub-step and the second half behind it.  DENSITY: h7 also feeds the density row of fc_8 in fp32.
+        auto seam_half = [&](auto half_tag, auto relu_tag, auto density_tag, auto next_blocks_tag, int l, const float *next_bias) {
+            constexpr int HALF_IX = decltype(half_tag)::value, NEXT_BLOCKS = decltype(next_blocks_tag)::value;
+            constexpr bool RELU = decltype(relu_tag)::value, DENSITY = decltype(density_tag)::value;
+            const float unscale = cb_[F2_CB_UNSCALE + l];
+#pragma unroll
+            for (int fb = 8 * HALF_IX; fb < 8 * HALF_IX + 8; ++fb) {
+                f32x4 x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[fb][r] * unscale;
+                    x[r] = RELU ? relu1(v) : v;
+                }
+                if (DENSITY) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(cb_ + CB_W8ROW0 + 16 * fb + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sigma_pre = fmaf(w[r], x[r], sigma_pre);
+                    asm volatile("" : "+v"(sigma_pre));   // here, not sunk to its use behind fc_9 (hipcc then parks all of h7 in scratch)
+                }
+                split4(x, act_hi[fb >> 1], act_lo[fb >> 1], fb & 1);
+                if (fb < NEXT_BLOCKS) acc[fb] = *reinterpret_cast<const f32x4 *>(next_bias + 16 * fb + 4 * g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        typedef std::integral_constant<int, 16> Full;
+        typedef std::integral_constant<int, 8> Half;
+        typedef std::integral_constant<int, 0> First;
+        typedef std::integral_constant<int, 1> Second;
+        typedef std::true_type Yes;
+        typedef std::false_type No;
+        // a 256 -> 256 layer whose inputs are the outputs of layer `prev` (ReLU in the seam): 8 sub-steps
+        auto plain_layer = [&](int prev, auto density_tag, const float *bias) {
+            seam_half(First(), Yes(), density_tag, Full(), prev, bias);
+            unsigned a = frag + pipe.acquire();
+            seam_half(Second(), Yes(), density_tag, Full(), prev, bias);
+            mma_kblock<16, PIECES, 0, F2_IMAGE_BYTES>(acc, act_hi[0], act_lo[0], a, pipe);
+            pipe.issue_done();
+#pragma unroll
+            for (int kb = 1; kb < 8; ++kb) sub_step(act_hi[kb], act_lo[kb]);
+        };
+
+        // ---- fc_in (nerf.py:102): sub-steps 0, 1
+        if (exact) {
+            encode_split<2, true>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo);
+            encode_split<1, true>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo);
+        } else {
+            encode_split<2, false>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo);
+            encode_split<1, false>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo);
+        }
+        load_bias_blocks(cb_ + CB_BIAS, 0, 16);
+        sub_step(pe_hi[0], pe_lo[0]);
+        sub_step(pe_hi[1], pe_lo[1]);
+        // ---- fc_1 .. fc_4 (:103-106)
+        for (int l = 1; l <= 4; ++l) plain_layer(l - 1, No(), cb_ + CB_BIAS + l * 256);
+        // ---- fc_5 on cat([pos, x]) (:108): position FIRST
+        {
+            seam_half(First(), Yes(), No(), Full(), 4, cb_ + CB_BIAS + 5 * 256);
+            unsigned a = frag + pipe.acquire();
+            seam_half(Second(), Yes(), No(), Full(), 4, cb_ + CB_BIAS + 5 * 256);
+            mma_kblock<16, PIECES, 0, F2_IMAGE_BYTES>(acc, pe_hi[0], pe_lo[0], a, pipe);
+            pipe.issue_done();
+            sub_step(pe_hi[1], pe_lo[1]);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) sub_step(act_hi[kb], act_lo[kb]);
+        }
+        // ---- fc_6, fc_7 (:109-110)
+        for (int l = 6; l <= 7; ++l) plain_layer(l - 1, No(), cb_ + CB_BIAS + l * 256);
+        // ---- fc_8 (:113): rows 1..256 on the matrix pipe; the density row from the fp32 h7 in the seam
+        plain_layer(7, Yes(), cb_ + CB_BIAS8);
+        // ---- fc_9 on cat([x[:,1:], view_dir]) (:116-118), 128 rows: two k-blocks of 8-KiB images per sub-step; fc_8 has
+        // no ReLU (:113)
+        {
+            seam_half(First(), No(), No(), Half(), 8, cb_ + CB_BIAS9);
+            unsigned a = frag + pipe.acquire();
+            seam_half(Second(), No(), No(), Half(), 8, cb_ + CB_BIAS9);
+            mma_kblock<8, PIECES, 0, F2_IMAGE_BYTES / 2>(acc, act_hi[0], act_lo[0], a, pipe);
+            mma_kblock<8, 0, F2_IMAGE_BYTES, 3 * F2_IMAGE_BYTES / 2>(acc, act_hi[1], act_lo[1], a, pipe);
+            pipe.issue_done();
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                a = frag + pipe.acquire();
+                mma_kblock<8, PIECES, 0, F2_IMAGE_BYTES / 2>(acc, act_hi[2 * j], act_lo[2 * j], a, pipe);
+                mma_kblock<8, 0, F2_IMAGE_BYTES, 3 * F2_IMAGE_BYTES / 2>(acc, act_hi[2 * j + 1], act_lo[2 * j + 1], a, pipe);
+                pipe.issue_done();
+            }
+            a = frag + pipe.acquire();
+            mma_kblock<8, PIECES, 0, F2_IMAGE_BYTES / 2>(acc, de_hi[0], de_lo[0], a, pipe);     // (+ a zero k-block: skipped)
+            pipe.issue_done();
+        }
+
+        // ---- ReLU(fc_9), fc_out, sigmoid (:118-119) and sigma = relu(x[:,0]) (:115), fp32 vector ALU
+        {
+            const float unscale = cb_[F2_CB_UNSCALE + 9];
+            float y[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int fb = 0; fb < 8; ++fb) {
+                f32x4 x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = relu1(acc[fb][r] * unscale);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(cb_ + CB_WOUT + c * HALF + 16 * fb + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[c] = fmaf(w[r], x[r], y[c]);
+                }
+            }
+            float sp = sigma_pre + __shfl_xor(sigma_pre, 16, WAVE);
+            sp += __shfl_xor(sp, 32, WAVE);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float p = y[c] + __shfl_xor(y[c], 16, WAVE);
+                p += __shfl_xor(p, 32, WAVE);
+                y[c] = 1.0f / (1.0f + expf(-(p + cb_[CB_SCALARS + 1 + c])));
+            }
+            if (valid && g == 0) {
+                sigma_out[m] = fmaxf(sp + cb_[CB_SCALARS], 0.0f);
+                rgb_out[3 * m + 0] = y[0];
+                rgb_out[3 * m + 1] = y[1];
+                rgb_out[3 * m + 2] = y[2];
+            }
+        }
+    }
+    if (!trailing) pipe.idle_step();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
+NERF_API int nerf_mlp_forward_f16x2(const nerf_net_t *net_abi, const void *packed_f16x2, const float *pos,
+                                    const float *view_dir, int64_t M, float *sigma, float *rgb, nerf_stream_t stream) {
+    mlp::Net net;
+    if (int rc = nerf::fused_net(net_abi, net, "nerf_mlp_forward_f16x2")) return rc;
+    if (!nerf::raw_inputs_ok(net))
+        return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_mlp_forward_f16x2: the kernel encodes raw points: nerf_net_t needs the "
+                                                "levels of both PositionalEncoders");
+    NERF_REQUIRE(M >= 0, "nerf_mlp_forward_f16x2: negative M");
+    if (M == 0) return NERF_OK;
+    NERF_REQUIRE(packed_f16x2 && pos && view_dir && sigma && rgb, "nerf_mlp_forward_f16x2: null pointer");
+    static nerf::DeviceMask configured = {0};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_forward_f16x2_kernel), F2_LDS_BYTES, configured,
+                                          "nerf_mlp_forward_f16x2: LDS attribute"))
+        return rc;
+    const int cus = nerf::device_cus();
+    const int64_t ntiles = (M + TILE - 1) / TILE;
+    hipLaunchKernelGGL(mlp_forward_f16x2_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(64 * WAVES), F2_LDS_BYTES,
+                       nerf::as_stream(stream), net, static_cast<const char *>(packed_f16x2), pos, view_dir, M, sigma, rgb);
+    return nerf::check_launch("nerf_mlp_forward_f16x2");
+}

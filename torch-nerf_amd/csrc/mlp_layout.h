@@ -189,6 +189,32 @@ constexpr int B16_SUBS = 37;
 constexpr int64_t B16_PACKED_BYTES = (int64_t)CONST_BYTES + (int64_t)B16_SUBS * B16_SUB_BYTES;
 __host__ __device__ constexpr int b16_frag_offset(int n, int slot) { return n * 64 + ((slot ^ ((n >> 2) & 3)) << 4); }
 
+// ---- split-f16 inference stream ("f16x2": fp32-grade results from the f16 matrix pipe, mlp_forward_f16x2.hip).
+// Every weight is scaled by its layer's power of two 2^s (max |W_l| -> [2^13, 2^14): the LOW part of a weight then stays
+// a normal f16 for every weight above 2^-16 of the largest) and split in two f16 parts, hi = f16(w), lo = f16(w - hi);
+// activations are split the same way in the layer seams and every k-step forms lo.hi + hi.lo + hi.hi on
+// v_mfma_f32_16x16x32_f16 (fp32 accumulate): 22 significand bits per operand, exact part products.
+// [const block (fp32)][sub-step 0] ... [sub-step 72]; a sub-step = 32 KiB = one LDS ring slot:
+//   256-row layers: ONE 32-wide k-block, [hi image 16 KiB][lo image 16 KiB]; an image = 256 rows x 64 B, row n holds four
+//     16-byte A fragments (8 f16), one per lane group g = lane >> 4: element e is W[n][32 kb + 16 (e>>2) + 4 g + (e&3)] --
+//     the features the D fragments of output blocks 2 kb and 2 kb + 1 (16 features each) of the previous layer hold in
+//     lane group g.  Fragment g of row n sits at slot g ^ ((n>>2)&3) (b16_frag_offset): conflict-free ds_read_b128.
+//   fc_9 (128 rows): images of 8 KiB, TWO k-blocks per sub-step: [hi kb][lo kb][hi kb+1][lo kb+1]
+//   subs 0,1      fc_in  (encoded position, two k-blocks)         subs 44..59   fc_6, fc_7
+//   subs 2..33    fc_1 .. fc_4  (8 per layer)                     subs 60..67   fc_8 rows 1..256
+//   subs 34,35    fc_5[:, 0:E_p]  (skip connection, pos first)    subs 68..71   fc_9[:, 0:256], two k-blocks each
+//   subs 36..43   fc_5[:, E_p:E_p+256]                            sub 72        fc_9[:, 256:256+E_d] (direction) + zeros
+// const block: the fp32 layout above with the biases PRE-SCALED by their layer's 2^s (the C fragment starts as the bias),
+// plus the ten factors 2^-s (layers fc_in .. fc_9) the seams multiply the accumulators with, and 2^s for the packer.
+constexpr int F2_IMAGE_BYTES = CHUNK_ROWS * CHUNK_K * 2;    // 16 KiB
+constexpr int F2_SUB_BYTES = 2 * F2_IMAGE_BYTES;            // 32 KiB
+constexpr int F2_SUBS = 73;
+constexpr int F2_SUB_FC5_POS = 34, F2_SUB_FC5 = 36, F2_SUB_FC6 = 44, F2_SUB_FC8 = 60, F2_SUB_FC9 = 68;
+constexpr int F2_CB_UNSCALE = CB_SCALARS + 4;               // 10 floats: 2^-s of fc_in .. fc_9
+constexpr int F2_CB_SCALE = F2_CB_UNSCALE + 10;             // 10 floats: 2^s
+static_assert(F2_CB_SCALE + 10 <= CONST_FLOATS, "const block");
+constexpr int64_t F2_PACKED_BYTES = (int64_t)CONST_BYTES + (int64_t)F2_SUBS * F2_SUB_BYTES;
+
 // physical byte offset, inside a chunk image, of the 16-byte slot holding
 // W[row n][k-group c] (c = (k % 32) / 4)
 __host__ __device__ constexpr int chunk_slot_offset(int n, int c) { return n * 128 + ((c ^ ((n >> 1) & 7)) << 4); }

@@ -152,6 +152,85 @@ __global__ void pack_bf16_kernel(const Params P, char *__restrict__ out) {
     }
 }
 
+
+// ---- split-f16 stream (mlp_layout.h "split-f16 inference stream")
+// pass 1, one block per matrix-pipe layer l = 0..9: s_l = 13 - floor(log2(max |W_l|)) (fc_8: rows 1..256 -- the density row
+// stays fp32 on the vector ALU), 2^-s and 2^s into the const block of the stream
+__global__ void f16x2_scale_kernel(const Params P, float *__restrict__ cblock) {
+    const int l = blockIdx.x;
+    const int rows = l == 8 ? FEAT : Net::layer_out(l), row0 = l == 8 ? 1 : 0, in = P.in[l];
+    __shared__ float red[256];
+    float m = 0.0f;
+    for (int e = threadIdx.x; e < rows * in; e += blockDim.x) m = fmaxf(m, fabsf(P.w(l, row0 + e / in, e % in)));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mx = red[0];
+        int s = 0;
+        if (mx > 0.0f && mx < INFINITY) {
+            s = 13 - ilogbf(mx);
+            s = s > 40 ? 40 : (s < -40 ? -40 : s);     // (all-tiny or huge layers: keep 2^s and the scaled biases finite)
+        }
+        cblock[F2_CB_UNSCALE + l] = ldexpf(1.0f, -s);
+        cblock[F2_CB_SCALE + l] = ldexpf(1.0f, s);
+    }
+}
+
+// (layer, output row offset, k) of stream position (sub, kbi = k-block inside the sub-step, kk); k < 0: zero filler
+__device__ float f16x2_stream_value(const Params &P, int sub, int kbi, int n, int kk, int &layer) {
+    const int E_POS = P.net.e_pos, E_DIR = P.net.e_dir;
+    if (sub < 2 || (sub >= F2_SUB_FC5_POS && sub < F2_SUB_FC5)) {     // encoded position into fc_in / fc_5 (pos first)
+        layer = sub < 2 ? 0 : 5;
+        const int k = 32 * (sub < 2 ? sub : sub - F2_SUB_FC5_POS) + kk;
+        return k < E_POS ? P.w(layer, n, k) : 0.0f;
+    }
+    if (sub < F2_SUB_FC5_POS) { layer = 1 + (sub - 2) / 8; return P.w(layer, n, 32 * ((sub - 2) % 8) + kk); }
+    if (sub < F2_SUB_FC6) { layer = 5; return P.w(5, n, E_POS + 32 * (sub - F2_SUB_FC5) + kk); }
+    if (sub < F2_SUB_FC8) { layer = 6 + (sub - F2_SUB_FC6) / 8; return P.w(layer, n, 32 * ((sub - F2_SUB_FC6) % 8) + kk); }
+    if (sub < F2_SUB_FC9) { layer = 8; return P.w(8, n + 1, 32 * (sub - F2_SUB_FC8) + kk); }
+    layer = 9;
+    const int ck = 2 * (sub - F2_SUB_FC9) + kbi;                      // k-block of fc_9; 8 = direction, 9 = filler
+    if (ck < 8) return P.w(9, n, 32 * ck + kk);
+    return (ck == 8 && kk < E_DIR) ? P.w(9, n, FEAT + kk) : 0.0f;
+}
+
+__global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
+    float *cblock = reinterpret_cast<float *>(out);
+    _Float16 *stream = reinterpret_cast<_Float16 *>(out + CONST_BYTES);
+    const int64_t n_f16 = (int64_t)F2_SUBS * F2_SUB_BYTES / 2;
+    const int64_t total = CONST_FLOATS + n_f16;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < CONST_FLOATS) {
+            if (e >= F2_CB_UNSCALE && e < F2_CB_SCALE + 10) continue;          // written by f16x2_scale_kernel
+            float v = const_block_value(P, (int)e);
+            if (e < CB_BIAS8) v *= cblock[F2_CB_SCALE + e / 256];             // biases ride in the scaled accumulators
+            else if (e < CB_BIAS9) v *= cblock[F2_CB_SCALE + 8];
+            else if (e < CB_W8ROW0) v *= cblock[F2_CB_SCALE + 9];
+            cblock[e] = v;
+            continue;
+        }
+        const int64_t r = e - CONST_FLOATS;                    // f16 element index in the stream
+        const int sub = (int)(r / (F2_SUB_BYTES / 2));
+        const int in_sub = (int)(r % (F2_SUB_BYTES / 2)) * 2;  // byte offset inside the sub-step
+        const int image_bytes = sub >= F2_SUB_FC9 ? F2_IMAGE_BYTES / 2 : F2_IMAGE_BYTES;
+        const int image = in_sub / image_bytes;                // 2 kbi + part (0 hi, 1 lo)
+        const int b = in_sub % image_bytes;                    // byte offset inside the image
+        const int n = b >> 6;                                  // row (64 B per row)
+        const int g = ((b & 63) >> 4) ^ ((n >> 2) & 3);        // logical fragment = lane group
+        const int el = (b & 15) >> 1;
+        const int kk = 16 * (el >> 2) + 4 * g + (el & 3);
+        int layer;
+        const float w = f16x2_stream_value(P, sub, image >> 1, n, kk, layer) * cblock[F2_CB_SCALE + layer];
+        const _Float16 hi = (_Float16)w;
+        stream[r] = (image & 1) ? (_Float16)(w - (float)hi) : hi;
+    }
+}
+
 }  // namespace
 
 NERF_API int nerf_mlp_path(const nerf_net_t *net) {
@@ -180,6 +259,23 @@ NERF_API int nerf_mlp_pack_bf16(const nerf_net_t *net, const float *params, void
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(1024), dim3(256), 0, nerf::as_stream(stream), P,
                        reinterpret_cast<char *>(packed));
     return nerf::check_launch("nerf_mlp_pack_bf16");
+}
+
+NERF_API int64_t nerf_mlp_packed_f16x2_bytes(const nerf_net_t *net) {
+    mlp::Net n;
+    return nerf::fused_net(net, n, "nerf_mlp_packed_f16x2_bytes") == NERF_OK ? mlp::F2_PACKED_BYTES : -1;
+}
+
+NERF_API int nerf_mlp_pack_f16x2(const nerf_net_t *net, const float *params, void *packed, nerf_stream_t stream) {
+    NERF_REQUIRE(params && packed, "nerf_mlp_pack_f16x2: null pointer");
+    Params P;
+    if (int rc = nerf::fused_net(net, P.net, "nerf_mlp_pack_f16x2")) return rc;
+    P.set(params);
+    hipLaunchKernelGGL(f16x2_scale_kernel, dim3(10), dim3(256), 0, nerf::as_stream(stream), P,
+                       reinterpret_cast<float *>(packed));
+    hipLaunchKernelGGL(pack_f16x2_kernel, dim3(1024), dim3(256), 0, nerf::as_stream(stream), P,
+                       reinterpret_cast<char *>(packed));
+    return nerf::check_launch("nerf_mlp_pack_f16x2");
 }
 
 NERF_API int64_t nerf_mlp_packed_bytes(const nerf_net_t *net) {

@@ -41,6 +41,9 @@ SIGNATURES = {
     "nerf_mlp_packed_bf16_bytes": (_c_i64, [_p]),
     "nerf_mlp_pack_bf16": (_c_int, [_p, _p, _p, _p]),
     "nerf_mlp_forward_bf16": (_c_int, [_p, _p, _p, _p, _c_i64, _p, _p, _p]),
+    "nerf_mlp_packed_f16x2_bytes": (_c_i64, [_p]),
+    "nerf_mlp_pack_f16x2": (_c_int, [_p, _p, _p, _p]),
+    "nerf_mlp_forward_f16x2": (_c_int, [_p, _p, _p, _p, _c_i64, _p, _p, _p]),
     "nerf_mlp_backward_workspace_bytes": (_c_i64, [_p, _c_i64]),
     "nerf_mlp_backward": (_c_int, [_p, _p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_mlp_layered_record_bytes": (_c_i64, [_p, _c_i64]),
@@ -104,7 +107,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.nerf_amd_abi_version() != 4:
+    if lib.nerf_amd_abi_version() != 5:
         raise RuntimeError("libnerf_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -248,6 +248,12 @@ class Net:
         return self.key == (63, 27, 256, 10, 1, 4, 1)
 
     @property
+    def f16x2_ok(self) -> bool:
+        """True if the split-f16 inference kernel (fp32-grade results on the f16 matrix pipe, csrc/mlp_forward_f16x2.hip)
+        serves this network: the fused family behind two PositionalEncoders."""
+        return self.fused and self.knows_encoders
+
+    @property
     def bf16_ok(self) -> bool:
         """True if the bf16-MFMA inference kernel serves this network (BASELINE configs[2]): the fused family behind two
         PositionalEncoders that share one include_input (the yaml has ONE such knob: positional_encoding.yaml:4)."""
@@ -297,6 +303,8 @@ KERNEL_EVENTS = None
 # what rocprofv3 calls the kernel behind the "render_pass" tag on the inference path (bench.py roofline object)
 DOMINANT_KERNEL = "render_fused_kernel (sampling + posenc + 11-layer MLP + integral in one kernel)"
 DOMINANT_KERNEL_BF16 = "mlp_forward_bf16_kernel (fused posenc + 11-layer MLP on v_mfma_f32_32x32x16_bf16)"
+DOMINANT_KERNEL_F16X2 = ("mlp_forward_f16x2_kernel (fused posenc + 11-layer MLP, operands split in two f16 parts, three "
+                         "v_mfma_f32_16x16x32_f16 per k-step)")
 
 
 def _timed(tag, M):
@@ -362,6 +370,43 @@ def mlp_forward_bf16(packed_bf16: torch.Tensor, pos: torch.Tensor, view_dir: tor
         end = _timed("mlp_forward_bf16", M)
         _lib.check(lib.nerf_mlp_forward_bf16(_ref(net), _ptr(packed_bf16), _ptr(pos), _ptr(view_dir), M, _ptr(sigma),
                                              _ptr(rgb), _stream()), "nerf_mlp_forward_bf16")
+        if end is not None:
+            end.record()
+    return sigma, rgb
+
+
+def mlp_pack_f16x2(flat_params: torch.Tensor, net: Optional[Net] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Flat fp32 state_dict blob -> split-f16 stream for mlp_forward_f16x2: every weight scaled by its layer's power of two
+    and split in two f16 parts (uint8 GPU tensor; `out` as in mlp_pack)."""
+    lib = _lib.load()
+    flat_params = _gpu(flat_params, "flat_params")
+    if flat_params.numel() != lib.nerf_mlp_param_count(_ref(net)):
+        raise ValueError(f"expected {lib.nerf_mlp_param_count(_ref(net))} parameters, got {flat_params.numel()}")
+    nbytes = lib.nerf_mlp_packed_f16x2_bytes(_ref(net))
+    if nbytes < 0:
+        raise RuntimeError(f"mlp_pack_f16x2: {lib.nerf_amd_last_error().decode()}")
+    packed = _pack_buffer(out, nbytes, flat_params.device, "mlp_pack_f16x2")
+    with torch.cuda.device(flat_params.device):
+        _lib.check(lib.nerf_mlp_pack_f16x2(_ref(net), _ptr(flat_params), _ptr(packed), _stream()), "nerf_mlp_pack_f16x2")
+    return packed
+
+
+def mlp_forward_f16x2(packed_f16x2: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor, net: Optional[Net] = None):
+    """Inference-only split-f16 variant of the fused encode + NeRF forward (the fp32 bound on the f16 matrix pipe);
+    pos, view_dir raw (M,3)."""
+    lib = _lib.load()
+    pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
+    _check_rows(pos, view_dir, False, net)
+    if not (isinstance(packed_f16x2, torch.Tensor) and packed_f16x2.is_cuda and packed_f16x2.is_contiguous()
+            and packed_f16x2.numel() * packed_f16x2.element_size() == lib.nerf_mlp_packed_f16x2_bytes(_ref(net))):
+        raise ValueError("mlp_forward_f16x2: `packed_f16x2` is not a mlp_pack_f16x2() stream of this library")
+    M = pos.shape[0]
+    sigma = torch.empty((M,), dtype=torch.float32, device=pos.device)
+    rgb = torch.empty((M, 3), dtype=torch.float32, device=pos.device)
+    with torch.cuda.device(pos.device):
+        end = _timed("mlp_forward_f16x2", M)
+        _lib.check(lib.nerf_mlp_forward_f16x2(_ref(net), _ptr(packed_f16x2), _ptr(pos), _ptr(view_dir), M, _ptr(sigma),
+                                              _ptr(rgb), _stream()), "nerf_mlp_forward_f16x2")
         if end is not None:
             end.record()
     return sigma, rgb
@@ -630,20 +675,25 @@ def render_is_fused(n_coarse: int, n_fine: int, fine: bool) -> bool:
 
 
 def render_rays(packed, ray_o, ray_d, t_bins, partition_size, u1, weights=None, u2=None, u3=None, bf16=False,
-                want_idx=False, want_t=False, net: Optional[Net] = None):
+                want_idx=False, want_t=False, net: Optional[Net] = None, f16x2=False):
     """One inference render_scene pass as a single enqueue -> (rgb (n,3), weights (n,S)[, idx (n,Sf)][, t (n,S)]).
     For the sample counts of the reference's configurations (64, 64+128) that is ONE kernel: sampling, the fused
     encode + MLP and the integral, with no intermediate in HBM.  `weights` (fine pass) is floored in place.
-    bf16=True: `packed` is a mlp_pack_bf16 stream and the MLP runs on the bf16 MFMA path (three launches)."""
-    if bf16:
+    bf16=True: `packed` is a mlp_pack_bf16 stream and the MLP runs on the bf16 MFMA path (three launches).
+    f16x2=True: `packed` is a mlp_pack_f16x2 stream and the MLP runs on the f16 matrix pipe with split operands -- the fp32
+    bound at three times the fp32 kernel's speed (three launches)."""
+    if bf16 and f16x2:
+        raise ValueError("render_rays: bf16 and f16x2 are two different MLP kernels, pick one")
+    if bf16 or f16x2:
         if want_idx or want_t:
-            raise ValueError("render_rays(bf16=True) returns (rgb, weights) only: ask sample_hierarchical for idx / t")
+            raise ValueError("render_rays(bf16 / f16x2) returns (rgb, weights) only: ask sample_hierarchical for idx / t")
         if weights is None:
             pts, dirs, delta = sample_stratified(ray_o, ray_d, t_bins, partition_size, u1)
         else:
             pts, dirs, delta = sample_hierarchical(ray_o, ray_d, t_bins, partition_size, weights, u1, u2, u3)
         n, S = delta.shape
-        sigma, rgb = mlp_forward_bf16(packed, pts.view(n * S, 3), dirs.view(n * S, 3), net=net)
+        fwd = mlp_forward_f16x2 if f16x2 else mlp_forward_bf16
+        sigma, rgb = fwd(packed, pts.view(n * S, 3), dirs.view(n * S, 3), net=net)
         return composite_forward(sigma.view(n, S), rgb.view(n, S, 3), delta)
     lib = _lib.load()
     ray_o, ray_d, t_bins, u1 = _gpu(ray_o, "ray_o"), _gpu(ray_d, "ray_d"), _gpu(t_bins, "t_bins"), _gpu(u1, "u1")

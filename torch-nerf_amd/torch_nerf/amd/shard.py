@@ -124,7 +124,8 @@ def _scene_parts(x):
 @torch.no_grad()
 def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, project_to_ndc: bool, seed: int,
                  group: Optional[dist.ProcessGroup] = None, rays_per_launch: int = 131072,
-                 bf16: bool = False, single_rank: bool = False, stats: Optional[dict] = None) -> torch.Tensor:
+                 bf16: bool = False, single_rank: bool = False, stats: Optional[dict] = None,
+                 f16x2: bool = False) -> torch.Tensor:
     """Full frame (H*W, 3) on every rank; each rank renders only its pixel range on its own GPU.
     stats (optional dict) receives what a slow N-GPU frame is diagnosed from: this rank's pixel range, its number of
     launches and two GPU events bracketing its own rendering, the collective excluded (`render_events`).
@@ -155,13 +156,15 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
         raise RuntimeError("render_frame: these networks are outside the fused family (feat_dim 256, pos_dim <= 64, "
                            "view_dir_dim <= 32 behind PositionalEncoders); pass the scene primitives (network + "
                            "encoders) instead of the bare networks so that the kernel chain can encode for them")
-    if bf16 and not fused:
-        raise RuntimeError("render_frame(bf16=True): the bf16 kernel serves the fused family only")
+    if (bf16 or f16x2) and not fused:
+        raise RuntimeError("render_frame(bf16 / f16x2): the bf16 and split-f16 kernels serve the fused family only")
     if fused:
         _, flat_c, packed_c = coarse_net._stream()
         _, flat_f, packed_f = fine_net._stream()
         if bf16:  # BASELINE configs[2]: bf16 weights / layer inputs on the bf16 MFMA path
             packed_c, packed_f = ops.mlp_pack_bf16(flat_c, spec_c), ops.mlp_pack_bf16(flat_f, spec_f)
+        if f16x2:  # the fp32 bound on the f16 matrix pipe (operands split in two f16 parts)
+            packed_c, packed_f = ops.mlp_pack_f16x2(flat_c, spec_c), ops.mlp_pack_f16x2(flat_f, spec_f)
     else:
         rays_per_launch = min(rays_per_launch, CHAIN_RAYS_PER_LAUNCH)
     out = torch.empty((hi - lo, 3), dtype=torch.float32, device=device)
@@ -179,10 +182,10 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
         bundle = sampler.generate_rays_from_pixels(camera, project_to_ndc, first=first, count=n, device=device)
         u1c, u1, u2, u3 = ray_draws(seed, first, n, n_coarse, n_fine, device)
         if fused:
-            rgb, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, bf16=bf16, net=spec_c)
+            rgb, w = ops.render_rays(packed_c, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c, bf16=bf16, net=spec_c, f16x2=f16x2)
             if n_fine > 0:     # n_fine == 0: coarse-only frame (BASELINE configs[0])
                 rgb, _ = ops.render_rays(packed_f, bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1, weights=w, u2=u2,
-                                         u3=u3, bf16=bf16, net=spec_f)
+                                         u3=u3, bf16=bf16, net=spec_f, f16x2=f16x2)
         else:
             pts, dirs, delta = ops.sample_stratified(bundle.ray_origin, bundle.ray_dir, t_bins, ps, u1c)
             sigma, radiance = coarse_scene.query_points(pts, dirs)

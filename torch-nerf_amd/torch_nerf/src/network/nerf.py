@@ -47,6 +47,11 @@ class NeRF(nn.Module):
         # BASELINE configs[2]: set to True to evaluate no-grad fused queries with bf16 weights and
         # bf16 layer inputs on the bf16 MFMA path (fp32 accumulate).  Training always runs in fp32.
         self.bf16_inference = False
+        # Round 6: set to True to evaluate no-grad fused queries on the f16 matrix pipe with every operand split in two
+        # f16 parts (three MFMAs per k-step, fp32 accumulate): the SAME 1e-5 bound as the fp32 kernels at ~3x their speed
+        # (csrc/mlp_forward_f16x2.hip).  Takes precedence over bf16_inference.  Training always runs in fp32.
+        self.f16x2_inference = False
+        self._packed_f16x2 = None
         self._flat_is_view = False
         self._rehome()
 
@@ -118,6 +123,13 @@ class NeRF(nn.Module):
         with torch.no_grad():
             self._packed_bf16 = ops.mlp_pack_bf16(flat, self._net, out=self._packed_bf16)
         return self._packed_bf16
+
+    def _stream_f16x2(self):
+        """The split-f16 stream of the current parameter values, re-packed per call like _stream's."""
+        _, flat, _ = self._stream()
+        with torch.no_grad():
+            self._packed_f16x2 = ops.mlp_pack_f16x2(flat, self._net, out=self._packed_f16x2)
+        return self._packed_f16x2
 
     @staticmethod
     def _blob_view(params):
@@ -212,6 +224,8 @@ class NeRF(nn.Module):
                 raise RuntimeError(f"NeRF({self._pos_dim}, {self._view_dir_dim}, {self._feat_dim}) has no fused query")
         input_grads = torch.is_grad_enabled() and (points.requires_grad or view_dirs.requires_grad)
         record = self._wants_grad(params) or input_grads
+        if self.f16x2_inference and not record and net.f16x2_ok:
+            return ops.mlp_forward_f16x2(self._stream_f16x2(), points, view_dirs, net)
         if self.bf16_inference and not record:
             if net.bf16_ok:
                 return ops.mlp_forward_bf16(self._stream_bf16(), points, view_dirs, net)

@@ -110,14 +110,17 @@ class VolumeRenderer(object):
         bf16 = bool(getattr(net, "bf16_inference", False)) and spec.bf16_ok
         if getattr(net, "bf16_inference", False) and not bf16:
             net.warn_bf16_ignored(spec)          # never silently fp32 when bf16 was asked for
-        if bf16:
+        f16x2 = bool(getattr(net, "f16x2_inference", False)) and spec.f16x2_ok      # (takes precedence over bf16)
+        if f16x2:
+            packed, bf16 = net._stream_f16x2(), False
+        elif bf16:
             packed = net._stream_bf16()
         if not hierarchical:
-            return ops.render_rays(packed, origin, direction, t_bins, partition_size, u1, bf16=bf16, net=spec)
+            return ops.render_rays(packed, origin, direction, t_bins, partition_size, u1, bf16=bf16, net=spec, f16x2=f16x2)
         w = weights.detach().to(dev)
         w_c = w if (w.is_contiguous() and w.dtype == torch.float32) else w.contiguous().float()
         out = ops.render_rays(packed, origin, direction, t_bins, partition_size, u1, weights=w_c, u2=u2, u3=u3,
-                              bf16=bf16, net=spec)
+                              bf16=bf16, net=spec, f16x2=f16x2)
         if w_c is not w:
             w.copy_(w_c)                                                     # keep the in-place side effect
         return out
