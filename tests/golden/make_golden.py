@@ -713,9 +713,101 @@ def f14_train_loop_l12_l5():
     f14_train_loop("f14_train_loop_l12_l5", (12, 5))
 
 
+# ---------------------------------------------------------------- F15 what the runners touch on the hot-path classes
+HOT_MODULES = ("torch_nerf.src.network", "torch_nerf.src.scene", "torch_nerf.src.renderer.cameras",
+               "torch_nerf.src.renderer.integrators.quadrature_integrator", "torch_nerf.src.renderer.ray_samplers",
+               "torch_nerf.src.renderer.volume_renderer", "torch_nerf.src.signal_encoder")
+HOT_CLASS_FILES = {      # class -> the reference file that defines it (public methods / properties / attributes read off it)
+    "VolumeRenderer": "torch_nerf/src/renderer/volume_renderer.py",
+    "PerspectiveCamera": "torch_nerf/src/renderer/cameras.py",
+    "StratifiedSampler": "torch_nerf/src/renderer/ray_samplers/stratified_sampler.py",
+    "RaySamplerBase": "torch_nerf/src/renderer/ray_samplers/sampler_base.py",
+    "QuadratureIntegrator": "torch_nerf/src/renderer/integrators/quadrature_integrator.py",
+    "PrimitiveCube": "torch_nerf/src/scene/primitives/cube.py",
+    "PrimitiveBase": "torch_nerf/src/scene/primitives/primitive_base.py",
+    "NeRF": "torch_nerf/src/network/nerf.py",
+    "PositionalEncoder": "torch_nerf/src/signal_encoder/positional_encoder.py",
+}
+RUNNER_FILES = ("torch_nerf/runners/runner_utils.py", "torch_nerf/runners/train.py", "torch_nerf/runners/render.py")
+
+
+def f15_runner_surface():
+    """The caller contract, read mechanically: an `ast` walk over the reference's three runner
+    files records every attribute they take from the seven hot-path modules (`network.NeRF`, `scene.scene` in
+    annotations, ...), the shape of every constructor call (positional count + keyword names), the shape of every call
+    of a public method the hot-path classes define (`render_scene(..., pixel_indices=, weights=, num_ray_batch=)`, ...)
+    and every member of those classes read or assigned on some object (`.radiance_field`, `.camera =`, ...).
+    tests/test_runner_surface.py checks each record against the drop-in with `hasattr` / `inspect.signature`.  Names
+    only -- no reference source text is stored."""
+    import ast
+    import json
+
+    # members of the hot-path classes, from their own definitions
+    methods, members = {}, {}
+    for cls, rel in HOT_CLASS_FILES.items():
+        tree = ast.parse(open(os.path.join(REFERENCE, rel)).read())
+        node = next(n for n in ast.walk(tree) if isinstance(n, ast.ClassDef) and n.name == cls)
+        for fn in node.body:
+            if not isinstance(fn, ast.FunctionDef):
+                continue
+            is_prop = any((isinstance(d, ast.Name) and d.id == "property") or
+                          (isinstance(d, ast.Attribute) and d.attr in ("setter", "getter")) for d in fn.decorator_list)
+            if is_prop:
+                members.setdefault(fn.name, set()).add(cls)
+            elif not fn.name.startswith("_"):
+                methods.setdefault(fn.name, set()).add(cls)
+            for sub in ast.walk(fn):        # instance attributes: self.x = ...
+                if isinstance(sub, ast.Attribute) and isinstance(sub.value, ast.Name) and sub.value.id == "self" and \
+                        isinstance(sub.ctx, ast.Store) and not sub.attr.startswith("_"):
+                    members.setdefault(sub.attr, set()).add(cls)
+    for generic in ("parameters", "state_dict", "load_state_dict", "to", "train", "eval"):    # nn.Module surface used on scenes
+        methods.setdefault(generic, set())
+
+    module_attrs, ctor_calls, method_calls, member_uses = {}, [], [], []
+    for rel in RUNNER_FILES:
+        tree = ast.parse(open(os.path.join(REFERENCE, rel)).read())
+        alias_mod, alias_cls = {}, {}
+        for n in ast.walk(tree):
+            if isinstance(n, ast.Import):
+                for a in n.names:
+                    if a.name in HOT_MODULES:
+                        alias_mod[a.asname or a.name.split(".")[-1]] = a.name
+            elif isinstance(n, ast.ImportFrom) and n.module in HOT_MODULES:
+                for a in n.names:
+                    alias_cls[a.asname or a.name] = (n.module, a.name)
+                    module_attrs.setdefault(n.module, set()).add(a.name)
+        for n in ast.walk(tree):
+            if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name) and n.value.id in alias_mod:
+                module_attrs.setdefault(alias_mod[n.value.id], set()).add(n.attr)
+            if isinstance(n, ast.Call):
+                shape = {"file": rel, "line": n.lineno, "nargs": len(n.args),
+                         "keywords": sorted(k.arg for k in n.keywords if k.arg is not None)}
+                f = n.func
+                if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id in alias_mod:
+                    ctor_calls.append(dict(shape, callee=alias_mod[f.value.id] + "." + f.attr))
+                elif isinstance(f, ast.Name) and f.id in alias_cls:
+                    ctor_calls.append(dict(shape, callee=".".join(alias_cls[f.id])))
+                elif isinstance(f, ast.Attribute) and f.attr in methods and \
+                        not (isinstance(f.value, ast.Name) and f.value.id in ("torch", "os", "self")):
+                    method_calls.append(dict(shape, method=f.attr, defined_by=sorted(methods[f.attr])))
+            if isinstance(n, ast.Attribute) and n.attr in members and \
+                    not (isinstance(n.value, ast.Name) and n.value.id in alias_mod):
+                member_uses.append({"file": rel, "line": n.lineno, "member": n.attr,
+                                    "store": isinstance(n.ctx, ast.Store), "defined_by": sorted(members[n.attr])})
+    rec = {"runner_files": list(RUNNER_FILES),
+           "module_attrs": {m: sorted(v) for m, v in sorted(module_attrs.items())},
+           "ctor_calls": sorted(ctor_calls, key=lambda c: (c["file"], c["line"], c["callee"])),
+           "method_calls": sorted(method_calls, key=lambda c: (c["file"], c["line"], c["method"])),
+           "member_uses": sorted(member_uses, key=lambda c: (c["file"], c["line"], c["member"], c["store"]))}
+    path = os.path.join(HERE, "f15_runner_surface.json")
+    json.dump(rec, open(path, "w"), indent=1, sort_keys=True)
+    print(f"wrote {path}: {sum(len(v) for v in rec['module_attrs'].values())} module attributes, {len(ctor_calls)} constructor "
+          f"calls, {len(method_calls)} method calls, {len(member_uses)} member uses")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    every = dict(f14=f14_train_loop, f14b=f14_train_loop_l12_l5, f13=f13_instant_ngp, f12=f12_sh_encoder, f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
+    every = dict(f15=f15_runner_surface, f14=f14_train_loop, f14b=f14_train_loop_l12_l5, f13=f13_instant_ngp, f12=f12_sh_encoder, f11=f11_net_variants, f10=f10_llff_poses, f9=f9_checkpoint, f1=f1_raygen, f2=f2_coarse, f3=f3_fine, f4=f4_posenc, f5=f5_mlp, f6=f6_composite, f7=f7_e2e,
                  f8=f8_adam)
     for name in (sys.argv[1:] or list(every)):      # e.g. `make_golden.py f8` rewrites one fixture
         every[name]()

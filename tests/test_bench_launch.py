@@ -119,3 +119,25 @@ def test_one_rank_rccl_collectives():
     frame = line["frame"]
     assert "error" not in frame, frame
     assert frame["equals_one_rank_image"] is True and frame["rays"] == 640000
+
+
+@pytest.mark.gpu
+def test_eight_ranks_on_one_gpu_through_the_real_kernels():
+    """The driver's rank count through the REAL kernels: eight ranks, all on the box's one GPU,
+    gloo between them -- every rank renders its own 4096-ray steps and its 80 000-pixel range of the 800x800 frame with
+    the fused render kernel, the slabs meet in the all-gather and the assembled image is the one-rank image bit for
+    bit.  (No scaling figure: eight processes share one GPU.)"""
+    first, line = _run("--gpus", "8", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                       "--no-train", "--no-bf16", "--no-f16x2", timeout=1500, lines_expected=2)
+    assert first["partial"] and "frame" not in first and first["value"] == line["value"] and "partial" not in line
+    assert line["n_gpus"] == 8 and line["rccl_ranks_seen"] == 8 and line["scaling"] == "weak"
+    assert line["config"]["global_rays_per_step"] == 8 * 4096 and line["value"] > 0
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and min(pr["ms_per_step"]) > 0 and 0 <= pr["rank_of_max"] < 8
+    frame = line["frame"]
+    assert "error" not in frame, frame
+    assert frame["rays"] == 640000 and frame["scaling"] == "strong"
+    assert frame["rays_per_rank"] == [80000] * 8 and frame["launches_per_rank"] == [1] * 8
+    assert len(frame["ms_per_rank"]) == 8 and min(frame["ms_per_rank"]) > 0 and frame["gather_ms"] > 0
+    assert frame["equals_one_rank_image"] is True
+    assert frame["image_sha256_16"] == frame["image_sha256_16_one_rank"]
