@@ -187,6 +187,11 @@ int nerf_mlp_backward(const nerf_net_t *net, const void *packed, const float *pa
 int64_t nerf_mlp_layered_record_bytes(const nerf_net_t *net, int64_t rows);
 int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t M);
 int64_t nerf_mlp_layered_plane(const nerf_net_t *net, int64_t rows, int which, int *width);
+/* Host-only dry run of nerf_mlp_layered_backward's bookkeeping (ABI v5; nothing launched, no GPU needed): the workspace
+ * layout, the dW work list against the budget the workspace was sized for, every window's destination rectangle and
+ * read extent, the partial-tile buffer on a device of `cus` compute units (<= 0: 256).  NERF_OK, or NERF_ERR_ARG with
+ * the failed check in nerf_amd_last_error(). */
+int nerf_mlp_layered_plan_check(const nerf_net_t *net, int64_t M, int cus);
 int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params, const float *pos, const float *view_dir,
                              int64_t M, int encoded, float *sigma, float *rgb, void *record, int64_t record_rows,
                              int keep_record, nerf_stream_t stream);

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libnerf_oracle.so")
+# NERF_ORACLE_SO: another build of the same source (the sanitized one of `make -C oracle asan`, tests/test_oracle_sanitized.py)
+_SO = os.environ.get("NERF_ORACLE_SO") or os.path.join(_HERE, "_build", "libnerf_oracle.so")
 _lib = None
 
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -21,6 +22,8 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (``make -C oracle``)."""
     src = os.path.join(_HERE, "nerf_oracle.c")
+    if os.environ.get("NERF_ORACLE_SO"):
+        return _SO          # built by whoever named it
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
     return _SO

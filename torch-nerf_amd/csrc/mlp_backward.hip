@@ -20,6 +20,7 @@
 //     scalar sums into the flat gradient blob (state_dict layout).  No atomics anywhere: gradients are
 //     reproducible bit for bit.
 #include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include <vector>
 
@@ -881,40 +882,44 @@ struct ListRing {
     void mark(int slot, hipStream_t s) {
         std::lock_guard<std::mutex> lock(mu);
         used[slot] = hipEventRecord(done[slot], s) == hipSuccess;
-        // (an event that cannot be recorded on this stream -- created under another device -- must not leave the slot
-        // looking free while its copy is in flight: drain the stream instead)
-        if (!used[slot]) (void)hipStreamSynchronize(s);
+        // (an event that cannot be recorded on this stream must not leave the slot looking free while its copy is in
+        // flight: drain the stream instead -- and clear the error just handled, or the check_launch behind the dW launch
+        // would report it as a launch failure)
+        if (!used[slot]) {
+            (void)hipStreamSynchronize(s);
+            (void)hipGetLastError();
+        }
     }
 };
-ListRing g_list_ring;
+constexpr int MAX_RING_DEVICES = 64;
+ListRing g_list_ring[MAX_RING_DEVICES];     // one per device ordinal: a slot's event is created under the device that uses it
 }  // namespace
 
-int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int64_t scratch_bytes, hipStream_t s) {
+// The host-only half of run_dw_items: descriptors, the tile -> workgroup map and what the list needs of the scratch
+// buffer.  No HIP call in here: nerf_mlp_layered_plan_check (mlp_layered.hip) runs it on a machine without a GPU, under
+// the CPU test suite, for every network shape -- the place where a latent overflow was found in round 5.
+struct DwPlan {
+    std::vector<GemmDesc> G;
+    float *base = nullptr;        // lowest destination pointer of the list: offsets are taken from it
+    int64_t units = 0, B = 0;     // work units of the list, workgroups of the launch
+    int64_t partial_floats = 0;   // partial tiles of all slices
+    int64_t list_bytes = 0;       // header + descriptors, rounded to 256
+    size_t host_bytes = 0;
+};
+static void plan_dw_items(const std::vector<DwItem> &items, int64_t M, int cus, DwPlan &P) {
     const int n = (int)items.size();
-    if (n == 0 || M <= 0) return NERF_OK;
-    static nerf::DeviceMask configured{0};
-    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_dw_list_kernel), DW_LDS_BYTES, configured,
-                                          "nerf_mlp_layered_backward: LDS attribute (dW)"))
-        return rc;
-    const int cus = nerf::device_cus();
     const int64_t MP = mlp::padded_rows(M), tiles = MP / 32;
-    // destination offsets are taken from the lowest destination pointer of the list
-    float *base = items[0].w_dst;
+    P.base = items[0].w_dst;
     for (const DwItem &it : items) {
-        if (it.w_dst < base) base = it.w_dst;
-        if (it.b_dst && it.b_dst < base) base = it.b_dst;
+        if (it.w_dst < P.base) P.base = it.w_dst;
+        if (it.b_dst && it.b_dst < P.base) P.base = it.b_dst;
     }
-    const size_t host_bytes = 16 + (size_t)n * sizeof(GemmDesc);
-    int slot = 0;
-    char *host = g_list_ring.take(host_bytes, &slot);
-    if (!host) return nerf::fail(NERF_ERR_LAUNCH, "nerf_mlp_layered_backward: pinned staging buffer for the dW item list");
-    GemmList *hdr = reinterpret_cast<GemmList *>(host);
-    GemmDesc *G = reinterpret_cast<GemmDesc *>(host + sizeof(GemmList));
-    static_assert(sizeof(GemmList) == 16, "header size");
+    P.host_bytes = 16 + (size_t)n * sizeof(GemmDesc);
+    P.G.resize(n);
     int64_t units = 0;
     for (int k = 0; k < n; ++k) {
         const DwItem &it = items[k];
-        GemmDesc &g = G[k];
+        GemmDesc &g = P.G[k];
         const int NA = it.a_blocks > 4 ? 2 : 1;
         const int KB = it.x_blocks > 4 ? 8 : it.x_blocks > 2 ? 4 : it.x_blocks > 1 ? 2 : 1;
         g.a_width = 128 * NA; g.x_width = 32 * KB;
@@ -927,7 +932,7 @@ int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int
         g.flags = it.b_dst ? FLAG_BIAS : 0;
         g.in_features = it.ld; g.col0 = 0; g.row0 = 0;
         g.valid_cols = it.cols_valid; g.valid_rows = it.rows_valid;
-        g.w_off = it.w_dst - base; g.b_off = it.b_dst ? it.b_dst - base : 0;
+        g.w_off = it.w_dst - P.base; g.b_off = it.b_dst ? it.b_dst - P.base : 0;
         // relative tile times by shape (measured for the fused family's four shapes, mlp_backward.hip:make_plan)
         const int nk = NA * KB;
         g.cost = nk == 16 ? 7350 : (NA == 1 && KB == 8) ? 3770 : (NA == 2 && KB == 2) ? 2010 : nk == 1 ? 935 : 450 * nk + 150;
@@ -938,8 +943,9 @@ int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int
         g.unit_off = units;
         units += tiles * g.cost;
     }
-    hdr->n = n; hdr->work_total = units;
+    P.units = units;
     const int64_t B = tiles * n < cus ? tiles * n : cus;
+    P.B = B;
     auto owner = [&](int64_t unit) {
         int64_t b = unit * B / units;
         while (b + 1 < B && units * (b + 1) / B <= unit) ++b;
@@ -948,22 +954,65 @@ int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int
     };
     int64_t off = 0;
     for (int k = 0; k < n; ++k) {
-        const int fb = owner(G[k].unit_off), lb = owner(G[k].unit_off + (tiles - 1) * G[k].cost);
-        G[k].first_block = fb; G[k].num_slices = lb - fb + 1; G[k].partial_off = off;
-        off += (int64_t)G[k].num_slices * ((int64_t)G[k].a_width * G[k].x_width + SLICE_EXTRA);
+        GemmDesc &g = P.G[k];
+        const int fb = owner(g.unit_off), lb = owner(g.unit_off + (tiles - 1) * g.cost);
+        g.first_block = fb; g.num_slices = lb - fb + 1; g.partial_off = off;
+        off += (int64_t)g.num_slices * ((int64_t)g.a_width * g.x_width + SLICE_EXTRA);
     }
-    const int64_t list_bytes = ((int64_t)host_bytes + 255) & ~(int64_t)255;
-    if (list_bytes + 4 * off > scratch_bytes)
+    P.partial_floats = off;
+    P.list_bytes = ((int64_t)P.host_bytes + 255) & ~(int64_t)255;
+}
+
+// bytes of the scratch buffer this list needs on a device of `cus` compute units (descriptor list + partial tiles)
+int64_t dw_items_needed_bytes(const std::vector<DwItem> &items, int64_t M, int cus) {
+    if (items.empty() || M <= 0 || cus <= 0) return 0;
+    DwPlan P;
+    plan_dw_items(items, M, cus, P);
+    return P.list_bytes + 4 * P.partial_floats;
+}
+
+// floats, counted from the start of its dY / X plane, up to which the dW kernel READS for this item: the last 32-sample
+// tile's window of the width the kernel works on (128 | 256 / a_split dY features, 32 | 64 | 128 | 256 X features), which
+// may be wider than what is left of the plane
+void dw_item_read_extent(const DwItem &it, int64_t M, int64_t *a_floats, int64_t *x_floats) {
+    const int64_t tiles = mlp::padded_rows(M) / 32;
+    const int NA = it.a_blocks > 4 ? 2 : 1;
+    const int KB = it.x_blocks > 4 ? 8 : it.x_blocks > 2 ? 4 : it.x_blocks > 1 ? 2 : 1;
+    const int a_split = it.a_blocks <= 1 ? 4 : it.a_blocks <= 2 ? 2 : 1;
+    *a_floats = (int64_t)it.a_fb0 * 1024 + (tiles - 1) * 32 * (int64_t)it.a_width + 32 * (int64_t)(128 * NA / a_split);
+    *x_floats = (int64_t)it.x_fb0 * 1024 + (tiles - 1) * 32 * (int64_t)it.x_width + 32 * (int64_t)(32 * KB);
+}
+
+int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int64_t scratch_bytes, hipStream_t s) {
+    const int n = (int)items.size();
+    if (n == 0 || M <= 0) return NERF_OK;
+    static nerf::DeviceMask configured{0};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_dw_list_kernel), DW_LDS_BYTES, configured,
+                                          "nerf_mlp_layered_backward: LDS attribute (dW)"))
+        return rc;
+    DwPlan P;
+    plan_dw_items(items, M, nerf::device_cus(), P);
+    if (P.list_bytes + 4 * P.partial_floats > scratch_bytes)
         return nerf::fail(NERF_ERR_ARG, "nerf_mlp_layered_backward: workspace too small for the dW partial tiles");
-    if (hipMemcpyAsync(scratch, host, host_bytes, hipMemcpyHostToDevice, s) != hipSuccess)
+    int slot = 0, device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= MAX_RING_DEVICES)
+        return nerf::fail(NERF_ERR_LAUNCH, "nerf_mlp_layered_backward: device ordinal outside the pinned-list rings");
+    ListRing &ring = g_list_ring[device];       // (events belong to the device they were created under: one ring each)
+    char *host = ring.take(P.host_bytes, &slot);
+    if (!host) return nerf::fail(NERF_ERR_LAUNCH, "nerf_mlp_layered_backward: pinned staging buffer for the dW item list");
+    GemmList *hdr = reinterpret_cast<GemmList *>(host);
+    static_assert(sizeof(GemmList) == 16, "header size");
+    memcpy(host + sizeof(GemmList), P.G.data(), (size_t)n * sizeof(GemmDesc));
+    hdr->n = n; hdr->work_total = P.units;
+    if (hipMemcpyAsync(scratch, host, P.host_bytes, hipMemcpyHostToDevice, s) != hipSuccess)
         return nerf::check_launch("nerf_mlp_layered_backward: item list upload");
-    g_list_ring.mark(slot, s);
+    ring.mark(slot, s);
     const GemmList *list = static_cast<const GemmList *>(scratch);
-    float *partial = reinterpret_cast<float *>(static_cast<char *>(scratch) + list_bytes);
-    hipLaunchKernelGGL(mlp_bwd_dw_list_kernel, dim3((unsigned)B), dim3(256), DW_LDS_BYTES, s, list, partial, M);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(scratch) + P.list_bytes);
+    hipLaunchKernelGGL(mlp_bwd_dw_list_kernel, dim3((unsigned)P.B), dim3(256), DW_LDS_BYTES, s, list, partial, M);
     if (int rc = nerf::check_launch("nerf_mlp_layered_backward: dW")) return rc;
     hipLaunchKernelGGL(mlp_bwd_reduce_list_kernel, dim3(64, n), dim3(256), 0, s, list,
-                       static_cast<const float *>(partial), base);
+                       static_cast<const float *>(partial), P.base);
     return nerf::check_launch("nerf_mlp_layered_backward: reduce");
 }
 }  // namespace nerf

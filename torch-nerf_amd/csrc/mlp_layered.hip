@@ -39,6 +39,8 @@ struct DwItem {
 };
 int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int64_t scratch_bytes, hipStream_t s);
 int64_t dw_items_scratch_bytes(int n_items);
+int64_t dw_items_needed_bytes(const std::vector<DwItem> &items, int64_t M, int cus);                      // host only
+void dw_item_read_extent(const DwItem &it, int64_t M, int64_t *a_floats, int64_t *x_floats);            // host only
 }  // namespace nerf
 
 #ifdef X_LAYERED_TIMELINE   // scripts/timeline_layered.py: where workgroup 0 / wavefront 0 of the general kernel spends its cycles
@@ -1610,6 +1612,117 @@ NERF_API int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t
     return z.dx_stream + z.planes + thin + nerf::dw_items_scratch_bytes(dw_item_budget(D)) + 65536;
 }
 
+// The dW / db work list of one backward call: windows of <= 256 x 256 over (dY plane of the layer, its input plane(s)).
+// Pure pointer arithmetic on the three bases -- nerf_mlp_layered_plan_check runs it with stand-in bases, no GPU.
+static void enumerate_dw_items(const Dims &D, int64_t MP, float *g_params, const float *rec, const float *grad,
+                               std::vector<nerf::DwItem> &items) {
+    auto add = [&](int layer, const float *dy_plane, int n_w, int rows_total, int row0, const float *x_plane, int x_w,
+                   int cols_total, int col0, bool bias) {
+        for (int fa = 0; fa * 32 < n_w; fa += 8)
+            for (int fx = 0; fx * 32 < x_w; fx += 8) {
+                nerf::DwItem it;
+                it.a_plane = dy_plane; it.a_width = n_w; it.a_fb0 = fa; it.a_blocks = n_w / 32 - fa < 8 ? n_w / 32 - fa : 8;
+                it.x_plane = x_plane; it.x_width = x_w; it.x_fb0 = fx; it.x_blocks = x_w / 32 - fx < 8 ? x_w / 32 - fx : 8;
+                it.ld = D.in[layer];
+                it.w_dst = g_params + D.w[layer] + (int64_t)(row0 + fa * 32) * D.in[layer] + col0 + fx * 32;
+                it.rows_valid = rows_total - fa * 32 < 256 ? rows_total - fa * 32 : 256;
+                it.cols_valid = cols_total - fx * 32 < 256 ? cols_total - fx * 32 : 256;
+                it.b_dst = (bias && fx == 0) ? g_params + D.b[layer] + row0 + fa * 32 : nullptr;
+                if (it.rows_valid > 0 && it.cols_valid > 0) items.push_back(it);
+            }
+    };
+    auto gp = [&](int off) { return grad + (int64_t)off * MP; };
+    auto rp = [&](int off) { return rec + (int64_t)off * MP; };
+    add(0, gp(D.g_dy(0)), D.Fp, D.F, 0, rp(D.r_pe()), D.Pp, D.E_p, 0, true);
+    for (int l = 1; l <= 8; ++l) {
+        if (l == 5) add(5, gp(D.g_dy(5)), D.Fp, D.F, 0, rp(D.r_pe()), D.Pp, D.E_p, 0, false);
+        add(l, gp(D.g_dy(l)), D.Fp, D.F, l == 8 ? 1 : 0, rp(D.r_h(l - 1)), D.Fp, D.F, l == 5 ? D.E_p : 0, true);
+    }
+    add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_h(8)), D.Fp, D.F, 0, true);
+    add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_de()), D.Dp, D.E_d, D.F, false);
+}
+
+// Host-only dry run of the backward call's bookkeeping for NeRF(net) on M samples and a device of `cus` compute units
+// (<= 0: 256, the MI355X): the workspace layout, the dW work list against dw_item_budget, every item's destination
+// rectangle against the parameter blob, every item's READ extent against the record / workspace it points into, and
+// the list's partial-tile buffer against what the workspace reserves for it.  Nothing is launched and no pointer is
+// dereferenced: tests/test_layered_plan.py sweeps it on the CPU (under the sanitizers too).
+NERF_API int nerf_mlp_layered_plan_check(const nerf_net_t *net, int64_t M, int cus) {
+    nerf_net_t d;
+    if (nerf::net_describe(net, d) < 0) return NERF_ERR_ARG;
+    NERF_REQUIRE(M >= 0 && M < (int64_t)1 << 31, "nerf_mlp_layered_plan_check: M out of range");
+    if (M == 0) return NERF_OK;
+    if (cus <= 0) cus = 256;
+    const Dims D = make_dims(d);
+    const int64_t MP = lrows(M);
+    const Sizes zr = sizes(D, M, false, 0), zw = sizes(D, M, true, 1);
+    const int64_t record_bytes = nerf_mlp_layered_record_bytes(net, M), workspace_bytes = nerf_mlp_layered_workspace_bytes(net, M);
+    const int64_t thin_bytes = align256b(8 * (int64_t)THIN_SLICES * (D.Fp + 3 * D.Hp + 4));
+    const int64_t dw_scratch_off = zw.dx_stream + zw.planes + thin_bytes;
+    const int64_t dw_scratch_bytes = nerf::dw_items_scratch_bytes(dw_item_budget(D)) + 65536;
+    char msg[256];
+#define PLAN_REQUIRE(cond, ...)                                     \
+    do {                                                            \
+        if (!(cond)) {                                              \
+            snprintf(msg, sizeof msg, __VA_ARGS__);                 \
+            return nerf::fail(NERF_ERR_ARG, msg);                   \
+        }                                                           \
+    } while (0)
+    PLAN_REQUIRE(record_bytes == zr.consts + zr.fwd_stream + zr.planes && zr.planes >= 4 * MP * (int64_t)D.recw(),
+                 "plan: record of %lld bytes does not hold %lld rows of %d floats", (long long)record_bytes, (long long)MP, D.recw());
+    PLAN_REQUIRE(zw.planes >= 4 * MP * (int64_t)D.gradw(), "plan: gradient planes");
+    PLAN_REQUIRE(dw_scratch_off + dw_scratch_bytes <= workspace_bytes, "plan: workspace of %lld bytes ends before the dW scratch (%lld + %lld)",
+                 (long long)workspace_bytes, (long long)dw_scratch_off, (long long)dw_scratch_bytes);
+    // stand-in bases, far apart: only differences are ever formed
+    char *const RECORD = reinterpret_cast<char *>((uintptr_t)1 << 44), *const WORK = reinterpret_cast<char *>((uintptr_t)2 << 44);
+    float *const PARAMS = reinterpret_cast<float *>((uintptr_t)3 << 44);
+    const float *rec = reinterpret_cast<const float *>(RECORD + zr.consts + zr.fwd_stream);
+    const float *grad = reinterpret_cast<const float *>(WORK + zw.dx_stream);
+    std::vector<nerf::DwItem> items;
+    enumerate_dw_items(D, MP, PARAMS, rec, grad, items);
+    PLAN_REQUIRE((int)items.size() <= dw_item_budget(D), "plan: %d dW windows, workspace sized for %d", (int)items.size(), dw_item_budget(D));
+    int64_t covered = 0;
+    for (size_t k = 0; k < items.size(); ++k) {
+        const nerf::DwItem &it = items[k];
+        // destination rectangle inside ONE layer's weight tensor
+        const int64_t w0 = it.w_dst - PARAMS;
+        int layer = -1;
+        for (int l = 0; l < 10; ++l)
+            if (w0 >= D.w[l] && w0 < D.w[l] + (int64_t)D.in[l] * D.out[l]) layer = l;
+        PLAN_REQUIRE(layer >= 0 && it.ld == D.in[layer], "plan: item %d writes outside every weight tensor", (int)k);
+        const int64_t rel = w0 - D.w[layer], row = rel / it.ld, col = rel % it.ld;
+        PLAN_REQUIRE(it.rows_valid >= 1 && it.rows_valid <= 256 && it.cols_valid >= 1 && it.cols_valid <= 256 &&
+                     row + it.rows_valid <= D.out[layer] && col + it.cols_valid <= D.in[layer],
+                     "plan: item %d (layer %d) writes rows %lld+%d of %d, columns %lld+%d of %d", (int)k, layer, (long long)row,
+                     it.rows_valid, D.out[layer], (long long)col, it.cols_valid, D.in[layer]);
+        covered += (int64_t)it.rows_valid * it.cols_valid;
+        if (it.b_dst) {
+            const int64_t b0 = it.b_dst - PARAMS;
+            PLAN_REQUIRE(b0 >= D.b[layer] && b0 + it.rows_valid <= D.b[layer] + D.out[layer], "plan: item %d bias rows", (int)k);
+        }
+        PLAN_REQUIRE(it.a_blocks >= 1 && it.a_blocks <= 8 && it.x_blocks >= 1 && it.x_blocks <= 8 &&
+                     it.a_blocks * 32 >= it.rows_valid && it.x_blocks * 32 >= it.cols_valid, "plan: item %d window blocks", (int)k);
+        // what the dW kernel reads: inside the buffer the plane lives in
+        int64_t a_floats = 0, x_floats = 0;
+        nerf::dw_item_read_extent(it, M, &a_floats, &x_floats);
+        const int64_t a_end = (reinterpret_cast<const char *>(it.a_plane) - WORK) + 4 * a_floats;
+        const int64_t x_end = (reinterpret_cast<const char *>(it.x_plane) - RECORD) + 4 * x_floats;
+        PLAN_REQUIRE(a_end <= workspace_bytes, "plan: item %d reads its dY window up to byte %lld of a %lld-byte workspace", (int)k,
+                     (long long)a_end, (long long)workspace_bytes);
+        PLAN_REQUIRE(x_end <= record_bytes, "plan: item %d reads its X window up to byte %lld of a %lld-byte record", (int)k,
+                     (long long)x_end, (long long)record_bytes);
+    }
+    // every element of the ten weight tensors (fc_8 without its density row, which the thin kernel owns) exactly once
+    int64_t want = 0;
+    for (int l = 0; l < 10; ++l) want += (int64_t)D.in[l] * (l == 8 ? D.out[l] - 1 : D.out[l]);
+    PLAN_REQUIRE(covered == want, "plan: the windows cover %lld weight elements of %lld", (long long)covered, (long long)want);
+    const int64_t need = nerf::dw_items_needed_bytes(items, M, cus);
+    PLAN_REQUIRE(need <= dw_scratch_bytes, "plan: the dW list needs %lld bytes of partial tiles, the workspace reserves %lld", (long long)need,
+                 (long long)dw_scratch_bytes);
+#undef PLAN_REQUIRE
+    return NERF_OK;
+}
+
 NERF_API int nerf_mlp_layered_forward(const nerf_net_t *net, const float *params, const float *pos,
                                       const float *view_dir, int64_t M, int encoded, float *sigma, float *rgb,
                                       void *record, int64_t record_rows, int keep_record, nerf_stream_t stream) {
@@ -1734,30 +1847,7 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
     }
     // dW / db: windows of <= 256 x 256 over (dY plane of the layer, its input plane(s))
     std::vector<nerf::DwItem> items;
-    auto add = [&](int layer, const float *dy_plane, int n_w, int rows_total, int row0, const float *x_plane, int x_w,
-                   int cols_total, int col0, bool bias) {
-        for (int fa = 0; fa * 32 < n_w; fa += 8)
-            for (int fx = 0; fx * 32 < x_w; fx += 8) {
-                nerf::DwItem it;
-                it.a_plane = dy_plane; it.a_width = n_w; it.a_fb0 = fa; it.a_blocks = n_w / 32 - fa < 8 ? n_w / 32 - fa : 8;
-                it.x_plane = x_plane; it.x_width = x_w; it.x_fb0 = fx; it.x_blocks = x_w / 32 - fx < 8 ? x_w / 32 - fx : 8;
-                it.ld = D.in[layer];
-                it.w_dst = g_params + D.w[layer] + (int64_t)(row0 + fa * 32) * D.in[layer] + col0 + fx * 32;
-                it.rows_valid = rows_total - fa * 32 < 256 ? rows_total - fa * 32 : 256;
-                it.cols_valid = cols_total - fx * 32 < 256 ? cols_total - fx * 32 : 256;
-                it.b_dst = (bias && fx == 0) ? g_params + D.b[layer] + row0 + fa * 32 : nullptr;
-                if (it.rows_valid > 0 && it.cols_valid > 0) items.push_back(it);
-            }
-    };
-    auto gp = [&](int off) { return grad + (int64_t)off * MP; };
-    auto rp = [&](int off) { return rec + (int64_t)off * MP; };
-    add(0, gp(D.g_dy(0)), D.Fp, D.F, 0, rp(D.r_pe()), D.Pp, D.E_p, 0, true);
-    for (int l = 1; l <= 8; ++l) {
-        if (l == 5) add(5, gp(D.g_dy(5)), D.Fp, D.F, 0, rp(D.r_pe()), D.Pp, D.E_p, 0, false);
-        add(l, gp(D.g_dy(l)), D.Fp, D.F, l == 8 ? 1 : 0, rp(D.r_h(l - 1)), D.Fp, D.F, l == 5 ? D.E_p : 0, true);
-    }
-    add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_h(8)), D.Fp, D.F, 0, true);
-    add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_de()), D.Dp, D.E_d, D.F, false);
+    enumerate_dw_items(D, MP, g_params, rec, grad, items);
     // (the bytes really left in the workspace nerf_mlp_layered_workspace_bytes sized, not a figure derived from the list)
     NERF_REQUIRE((int)items.size() <= dw_item_budget(D), "nerf_mlp_layered_backward: more dW windows than the workspace was sized for");
     return nerf::run_dw_items(items, M, dw_scratch, nerf::dw_items_scratch_bytes(dw_item_budget(D)) + 65536, s);
