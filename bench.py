@@ -775,7 +775,7 @@ def configs_leg(nets, flats, device):
     return out
 
 
-def encoder_variants_leg(device, local_rank, steps, warmup):
+def encoder_variants_leg(device, local_rank, steps, warmup, renderer=None):
     """Whole-pass rays/s -- sampling + encoder kernel + network kernel + integral, coarse then fine, through
     VolumeRenderer.render_scene exactly like the headline step -- for the encoder settings the reference's yaml can
     name beyond the shipped 10 / 4 (configs/signal_encoder/positional_encoding.yaml:2-3, sh.yaml; runner_utils.py:584-612
@@ -788,8 +788,12 @@ def encoder_variants_leg(device, local_rank, steps, warmup):
     import torch_nerf.src.scene as scene
     from torch_nerf.src.signal_encoder import PositionalEncoder, SHEncoder
     from torch_nerf.amd import shard, synth
-    renderer = build_scene(device)[0]
+    if renderer is None:
+        renderer = build_scene(device)[0]
     cam = renderer.camera
+    # the legs behind this one (bf16, f16x2, train) must draw what they would draw without it: the global generators'
+    # states are restored on the way out
+    rng_cpu, rng_gpu = torch.get_rng_state(), torch.cuda.get_rng_state(device)
     pix = [((torch.arange(RAYS, device=device) + s * RAYS) % (H * W)) for s in range(warmup + steps)]
     variants = {"coord_l12": (PositionalEncoder(3, 12, True), PositionalEncoder(3, 4, True)),
                 "dir_l5": (PositionalEncoder(3, 10, True), PositionalEncoder(3, 5, True)),
@@ -853,6 +857,8 @@ def encoder_variants_leg(device, local_rank, steps, warmup):
     out["what"] = ("4096 rays x (64+128), fp32, coarse + fine render_scene per step (the headline step's two calls) behind "
                    "non-default encoders: kernel chain sampling -> encode -> network -> integral; frame = 800x800 via "
                    "shard.render_frame(scenes)")
+    torch.set_rng_state(rng_cpu)
+    torch.cuda.set_rng_state(rng_gpu, device)
     return out
 
 
@@ -1210,7 +1216,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_configs:     # before the train leg: that one UPDATES the networks
         result["configs"] = guarded("configs", lambda: configs_leg(nets, flats, device))
     if rank == 0 and world == 1 and not args.no_configs:
-        result["encoders"] = guarded("encoders", lambda: encoder_variants_leg(device, local_rank, max(5, args.steps // 4), 2))
+        result["encoders"] = guarded("encoders", lambda: encoder_variants_leg(device, local_rank, max(5, args.steps // 4), 2, renderer))
         if isinstance(result.get("configs"), dict) and "error" not in result["encoders"]:
             # the same three whole-pass figures beside the other BASELINE configurations (VERDICT r04 item 4 asked for them
             # there); the full objects -- training step, frame -- stay under `encoders`

@@ -36,11 +36,14 @@ ASM_MNEMONICS = {
     "ds_write_b32": ("mfma-d",), "ds_write_b128": ("mfma-d",),
     "v_max_f32": ("mfma-d",), "v_min_u32": ("mfma-d",), "v_bfe_i32": ("mfma-d",), "v_fmac_f32": ("mfma-d",),
     "v_pk_max_i16": ("mfma-d",),
+    # split-f16 kernel (mlp_forward_f16x2.hip): range tracking and the hand-written hi / lo split
+    "v_max3_f32": ("mfma-d",), "v_cvt_pk_f16_f32": ("mfma-d",), "v_fma_mix_f32": ("mfma-d",),
 }
 MFMA_WAIT_STATES = 18
 
 
 def regs(tok):
+    tok = tok.lstrip("-").strip("|")          # source modifiers: -v3, |v9|, -|v9|
     m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
     if m:
         return set(range(int(m.group(1)), int(m.group(2)) + 1))

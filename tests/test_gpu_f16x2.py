@@ -196,12 +196,23 @@ def test_huge_arguments_take_the_library_sincos_and_overflow_is_loud():
     # (a raw coordinate of 3200 is carried to 2^-22 of ITS size by the two f16 parts -- 7.6e-4 -- where fp32 has 2^-24:
     # relative to the resulting sigma of 50 .. 260 that is 4e-6)
     assert float(((s - s32).abs() / s32.abs().clamp(min=1.0)).max()) <= ATOL
-    pts[5, 1] = 1.0e5
-    s, c = ops.mlp_forward_f16x2(packed, dev(pts), dev(dirs))
-    assert not (torch.isfinite(s[5]) and torch.isfinite(c[5]).all())
-    keep = torch.ones(M, dtype=torch.bool, device="cuda")
-    keep[0:16] = False                                  # (the overflowing sample's wavefront runs the library path with it)
-    assert float((c[keep] - c32[keep]).abs().max()) <= GOLDEN_ATOL
+    # beyond the f16 range the hi part would be inf, the next accumulator inf - inf = NaN and the ReLU behind it 0 -- a
+    # finite, wrong answer; the kernel follows the largest magnitude it splits per sample and returns NaN instead
+    for bad in (1.0e5, 7.0e4, -3.0e6):
+        q = pts.copy()
+        q[5, 1] = bad
+        s, c = ops.mlp_forward_f16x2(packed, dev(q), dev(dirs))
+        assert torch.isnan(s[5]) and torch.isnan(c[5]).all(), bad
+        keep = torch.ones(M, dtype=torch.bool, device="cuda")
+        keep[5] = False                                 # every other sample -- its wavefront neighbours included -- is untouched
+        assert torch.isfinite(s[keep]).all() and float((c[keep] - c32[keep]).abs().max()) <= GOLDEN_ATOL
+    # ... and an ACTIVATION that leaves the range (weights blown up by 2^12: h0 ~ 1e4, h1 ~ 1e8)
+    big = synth.nerf_flat_params(seed=3, sigma_bias=1.0, sigma_gain=30.0)
+    p = synth.split_flat_params(big)
+    p["fc_in.weight"] *= 4096.0
+    p["fc_1.weight"] *= 4096.0
+    s, c = ops.mlp_forward_f16x2(ops.mlp_pack_f16x2(dev(big)), dev(pts[:64]), dev(dirs[:64]))
+    assert torch.isnan(s).any() and not torch.isinf(s).any()
 
 
 def test_sharded_frame_on_the_split_kernel_equals_the_fp32_frame_to_the_bound():

@@ -92,7 +92,7 @@ def test_fused_query_with_runtime_levels(golden, tag):
     flat, dims = variant_params(g, tag)
     net = make_net(flat, dims)
     cube = scene.PrimitiveCube(net, {"coord_enc": PositionalEncoder(3, lp, inc), "dir_enc": PositionalEncoder(3, ld, inc)})
-    assert cube.fused_query and cube.fused_net().key == (*dims, lp, int(inc), ld, int(inc))
+    assert cube.raw_net() is not None and cube.fused_net().key == (*dims, lp, int(inc), ld, int(inc))
     M = g["pts"].shape[0]
     pts, dirs = dev(g["pts"]).view(M // 4, 4, 3), dev(g["dirs"]).view(M // 4, 4, 3)
     with torch.no_grad():

@@ -16,13 +16,15 @@
 //     64 = 256 registers before the first temporary.)
 //   * workgroup = 8 wavefronts = 128 samples per pass; weights scaled per layer by a power of two, split at pack time
 //     (mlp_pack.hip), streamed in 32-KiB sub-steps [hi image | lo image] of one 32-wide k-block through the bf16 kernel's
-//     4-slot LDS ring, the two halves of the workgroup one sub-step apart; 73 sub-steps per tile.  An A fragment is
-//     one ds_read_b128; the hi fragment feeds two MFMAs, the lo fragment one: 2 KiB of LDS reads per 3 MFMAs
+//     4-slot LDS ring; 73 sub-steps per tile.  An A fragment is one ds_read_b128 out of an image swizzled for the lane
+//     sets ds_read_b128 serves together (mlp_layout.h:f2_frag_offset; zero bank conflicts, profiles/r06_pmc_f16x2.txt);
+//     the hi fragment feeds two MFMAs, the lo fragment one: 2 KiB of LDS reads per 3 MFMAs
 //   * encodings in fp32 (one accurate sincos per needed feature, the library path for huge arguments, like the fp32
 //     kernels), split like every other activation; biases ride pre-scaled in the C fragment; the density row of fc_8
 //     (from the unsplit fp32 h7), fc_out and the sigmoid stay fp32 on the vector ALU
 // Every network of the fused family behind two PositionalEncoders (run-time levels / include_input).  Inference only.
-// Range: activations beyond +-65504 overflow the hi part (-> inf / NaN in the outputs, never a silent wrong value).
+// Range: an input, encoding or activation beyond +-65504 cannot be split; the kernel tracks the largest magnitude it
+// splits per sample and returns NaN for such a sample (never a silent wrong value).
 #include <type_traits>
 
 #include "mlp_device.h"
@@ -95,14 +97,17 @@ __device__ __forceinline__ f16x8 lds_read_fragment16(unsigned lds_addr, int imm_
 template <int NFB, int N_PIECES, int HI_OFF, int LO_OFF>
 __device__ __forceinline__ void mma_kblock(f32x4 (&acc)[16], const f16x8 &bhi, const f16x8 &blo, unsigned addr,
                                            const SubPipe &pipe) {
-    constexpr int PAIRS = NFB / 2, AHEAD = 2, EVERY = N_PIECES > 0 ? PAIRS / N_PIECES : 1;
+#ifndef X_F2_AHEAD
+#define X_F2_AHEAD 2          // A/B knob: pairs of output blocks whose A fragments are in flight ahead of the MFMAs
+#endif
+    constexpr int PAIRS = NFB / 2, AHEAD = X_F2_AHEAD, NBUF = AHEAD + 1, EVERY = N_PIECES > 0 ? PAIRS / N_PIECES : 1;
     static_assert(NFB % 2 == 0 && (N_PIECES == 0 || PAIRS % N_PIECES == 0), "pairs of output blocks; pieces divide them");
-    f16x8 ah[3][2], al[3][2];
+    f16x8 ah[NBUF][2], al[NBUF][2];
     auto fetch = [&](int p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            ah[p % 3][j] = lds_read_fragment16(addr, HI_OFF + (2 * p + j) * 1024);
-            al[p % 3][j] = lds_read_fragment16(addr, LO_OFF + (2 * p + j) * 1024);
+            ah[p % NBUF][j] = lds_read_fragment16(addr, HI_OFF + (2 * p + j) * 1024);
+            al[p % NBUF][j] = lds_read_fragment16(addr, LO_OFF + (2 * p + j) * 1024);
         }
     };
 #pragma unroll
@@ -111,11 +116,16 @@ __device__ __forceinline__ void mma_kblock(f32x4 (&acc)[16], const f16x8 &bhi, c
     for (int p = 0; p < PAIRS; ++p) {
         // pairs p+1 .. p+AHEAD-1 may still be in flight: four reads each
         __builtin_amdgcn_sched_barrier(0);
-        if (p + 1 < PAIRS) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            constexpr int LEFT[3] = {0, 4, 8};
+            const int younger = (PAIRS - 1 - p) < (AHEAD - 1) ? (PAIRS - 1 - p) : (AHEAD - 1);
+            if (LEFT[younger] == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else if (LEFT[younger] == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (p + AHEAD < PAIRS) fetch(p + AHEAD);
-        const int b = p % 3, f0 = 2 * p, f1 = 2 * p + 1;
+        const int b = p % NBUF, f0 = 2 * p, f1 = 2 * p + 1;
         acc[f0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b][0], bhi, acc[f0], 0, 0, 0);
         acc[f1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b][1], bhi, acc[f1], 0, 0, 0);
         acc[f0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b][0], blo, acc[f0], 0, 0, 0);
@@ -127,7 +137,32 @@ __device__ __forceinline__ void mma_kblock(f32x4 (&acc)[16], const f16x8 &bhi, c
 }
 
 // x (fp32, four features of one output block) -> elements 4 half .. 4 half + 3 of the hi / lo B fragments
-__device__ __forceinline__ void split4(const f32x4 &x, f16x8 &hi, f16x8 &lo, int half) {
+// `amax` follows the largest |x| this lane has split: beyond 65504 the hi part is inf, inf - inf = NaN in the next
+// accumulator and the ReLU behind it turns that into 0 -- a finite, wrong output.  The kernel poisons such a sample.
+__device__ __forceinline__ void split4(const f32x4 &x, f16x8 &hi, f16x8 &lo, int half, float &amax) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(x[0]), "v"(x[1]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(x[2]), "v"(x[3]));
+#ifndef X_F2_PLAINSPLIT    // the residual x - hi as ONE v_fma_mix_f32 per value, hi read as an f16 operand in place (hipcc's own
+                          // sequence converts hi back to fp32 first: 5 instead of 3.5 instructions per value, 3 % of the kernel --
+                          // profiles/r06_ab_f16x2.txt; X_F2_PLAINSPLIT builds that one for A/B)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 H = __builtin_bit_cast(u32x4, hi), L = __builtin_bit_cast(u32x4, lo);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        unsigned hp, lp;
+        float r0, r1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
+        // d = 1.0 * x - hi:  v_fma_mix_f32 d, x, 1.0, -hi(f16, low | high half of hp)
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x[2 * j]), "v"(hp));
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x[2 * j + 1]), "v"(hp));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp) : "v"(r0), "v"(r1));
+        H[2 * half + j] = hp;
+        L[2 * half + j] = lp;
+    }
+    hi = __builtin_bit_cast(f16x8, H);
+    lo = __builtin_bit_cast(f16x8, L);
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const _Float16 h = (_Float16)x[r];
@@ -141,7 +176,7 @@ __device__ __forceinline__ void split4(const f32x4 &x, f16x8 &hi, f16x8 &lo, int
 // `width` = out_dim on
 template <int NKB, bool EXACT>
 __device__ __forceinline__ void encode_split(float x, float y, float z, int g, int width, int include_input,
-                                             f16x8 (&hi)[NKB], f16x8 (&lo)[NKB]) {
+                                             f16x8 (&hi)[NKB], f16x8 (&lo)[NKB], float &amax) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -149,7 +184,7 @@ __device__ __forceinline__ void encode_split(float x, float y, float z, int g, i
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = enc_feature<EXACT>(32 * kb + 16 * half + 4 * g + r, x, y, z, width, include_input);
-            split4(v, hi[kb], lo[kb], half);
+            split4(v, hi[kb], lo[kb], half, amax);
         }
 }
 
@@ -170,7 +205,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
         reinterpret_cast<f32x4 *>(cb_)[e] = reinterpret_cast<const f32x4 *>(packed)[e];
 
     // A fragment of output block fb, lane (row n of the block, lane group g): row 16 fb + n, logical slot g
-    const unsigned frag = ring + (unsigned)b16_frag_offset(n, g);
+    const unsigned frag = ring + (unsigned)f2_frag_offset(n, g);
 
     SubPipe pipe;
     pipe.src_wave = packed + CONST_BYTES + wave * (PIECES * 1024);
@@ -186,7 +221,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
         for (int p = 0; p < PIECES; ++p) pipe.issue_piece(p);
         pipe.issue_done();
     }
-    if (trailing) pipe.idle_step();
+    // The bf16 kernel runs the two halves of the workgroup one sub-step apart so that one wave's seam falls under its SIMD
+    // partner's MFMAs.  Here the waves drift apart on their own (a seam is 1/6 of a layer, not 1/3) and the in-phase
+    // schedule measures 0.4 - 1.4 % faster (profiles/r06_ab_f16x2.txt); X_F2_LAG builds the lagged one for A/B.
+#ifdef X_F2_LAG
+    const bool lag = true;
+#else
+    const bool lag = false;
+#endif
+    if (trailing && lag) pipe.idle_step();
 
     const int64_t ntiles = (M + TILE - 1) / TILE;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -207,6 +250,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
         f16x8 pe_hi[2], pe_lo[2];      // the encoded position: fc_in and the fc_5 skip connection
         f16x8 de_hi[1], de_lo[1];      // the encoded direction (fc_9): evaluated up front too, while nothing else is live
         float sigma_pre = 0.0f;
+        float amax = 0.0f;             // largest magnitude split so far (f16 range check, see split4)
         // (the lane group as a value hipcc cannot reason about: the feature-index arithmetic of the encodings would
         // otherwise be hoisted out of the tile loop and held in ~50 registers across the whole MFMA stream)
         int ge = g;
@@ -246,7 +290,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
                     for (int r = 0; r < 4; ++r) sigma_pre = fmaf(w[r], x[r], sigma_pre);
                     asm volatile("" : "+v"(sigma_pre));   // here, not sunk to its use behind fc_9 (hipcc then parks all of h7 in scratch)
                 }
-                split4(x, act_hi[fb >> 1], act_lo[fb >> 1], fb & 1);
+                split4(x, act_hi[fb >> 1], act_lo[fb >> 1], fb & 1, amax);
                 if (fb < NEXT_BLOCKS) acc[fb] = *reinterpret_cast<const f32x4 *>(next_bias + 16 * fb + 4 * g);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -270,11 +314,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
 
         // ---- fc_in (nerf.py:102): sub-steps 0, 1
         if (exact) {
-            encode_split<2, true>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo);
-            encode_split<1, true>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo);
+            encode_split<2, true>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo, amax);
+            encode_split<1, true>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo, amax);
         } else {
-            encode_split<2, false>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo);
-            encode_split<1, false>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo);
+            encode_split<2, false>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo, amax);
+            encode_split<1, false>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo, amax);
         }
         load_bias_blocks(cb_ + CB_BIAS, 0, 16);
         sub_step(pe_hi[0], pe_lo[0]);
@@ -335,6 +379,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
             }
             float sp = sigma_pre + __shfl_xor(sigma_pre, 16, WAVE);
             sp += __shfl_xor(sp, 32, WAVE);
+            amax = fmaxf(amax, __shfl_xor(amax, 16, WAVE));
+            amax = fmaxf(amax, __shfl_xor(amax, 32, WAVE));
+            const bool overflow = !(amax <= 65504.0f);      // an input, encoding or activation of this sample left the f16 range
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float p = y[c] + __shfl_xor(y[c], 16, WAVE);
@@ -342,14 +389,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
                 y[c] = 1.0f / (1.0f + expf(-(p + cb_[CB_SCALARS + 1 + c])));
             }
             if (valid && g == 0) {
-                sigma_out[m] = fmaxf(sp + cb_[CB_SCALARS], 0.0f);
-                rgb_out[3 * m + 0] = y[0];
-                rgb_out[3 * m + 1] = y[1];
-                rgb_out[3 * m + 2] = y[2];
+                const float poison = overflow ? __builtin_nanf("") : 0.0f;    // loud, never a silent wrong value
+                sigma_out[m] = fmaxf(sp + cb_[CB_SCALARS], 0.0f) + poison;
+                rgb_out[3 * m + 0] = y[0] + poison;
+                rgb_out[3 * m + 1] = y[1] + poison;
+                rgb_out[3 * m + 2] = y[2] + poison;
             }
         }
     }
-    if (!trailing) pipe.idle_step();
+    if (!trailing && lag) pipe.idle_step();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

@@ -362,8 +362,11 @@ __global__ __launch_bounds__(256) void encode_to_plane_kernel(const float *__res
             const float v = m < M ? x[3 * m + c] : 0.0f;
             if (inc && fq == 0) { t[r * ld + c] = m < M ? v : 0.0f; continue; }
             const int f = fq - (inc ? 1 : 0);
-            float sn, cs;
-            sincosf(ldexpf(v, f), &sn, &cs);               // 2^f * x, exact (:81, :87-88)
+            // sinf and cosf SEPARATELY, like posenc.hip (and posenc_backward): the raw entry is documented bit-identical to
+            // PositionalEncoder.encode + the pre-encoded entry, and sincosf returning the same bits as the two calls is a
+            // property of one ROCm device library, probed for 16 of the ~42 octaves this entry admits
+            const float arg = ldexpf(v, f);                // 2^f * x, exact (:81, :87-88)
+            const float sn = sinf(arg), cs = cosf(arg);
             t[r * ld + raw + 6 * f + c] = m < M ? sn : 0.0f;
             t[r * ld + raw + 6 * f + 3 + c] = m < M ? cs : 0.0f;
         }

@@ -198,7 +198,11 @@ __host__ __device__ constexpr int b16_frag_offset(int n, int slot) { return n * 
 //   256-row layers: ONE 32-wide k-block, [hi image 16 KiB][lo image 16 KiB]; an image = 256 rows x 64 B, row n holds four
 //     16-byte A fragments (8 f16), one per lane group g = lane >> 4: element e is W[n][32 kb + 16 (e>>2) + 4 g + (e&3)] --
 //     the features the D fragments of output blocks 2 kb and 2 kb + 1 (16 features each) of the previous layer hold in
-//     lane group g.  Fragment g of row n sits at slot g ^ ((n>>2)&3) (b16_frag_offset): conflict-free ds_read_b128.
+//     lane group g.  Fragment g of row n sits at slot g ^ sigma((n>>2)&3), sigma = (0, 2, 3, 1) (f2_frag_offset):
+//     ds_read_b128 serves the lanes {0-3, 12-15, 20-23, 24-27} | {4-7, 8-11, 16-19, 28-31} | the same + 32 together, and
+//     with lane = 16 g + (row & 15) the bf16 stream's sigma = identity puts two row quads of such a set on the same
+//     banks (PMC: 48 % of the LDS-active cycles were bank conflicts, profiles/r06_pmc_f16x2_first_cut.txt);
+//     scripts/lds_b128_probe.hip times all 24 sigma.
 //   fc_9 (128 rows): images of 8 KiB, TWO k-blocks per sub-step: [hi kb][lo kb][hi kb+1][lo kb+1]
 //   subs 0,1      fc_in  (encoded position, two k-blocks)         subs 44..59   fc_6, fc_7
 //   subs 2..33    fc_1 .. fc_4  (8 per layer)                     subs 60..67   fc_8 rows 1..256
@@ -214,6 +218,8 @@ constexpr int F2_CB_UNSCALE = CB_SCALARS + 4;               // 10 floats: 2^-s o
 constexpr int F2_CB_SCALE = F2_CB_UNSCALE + 10;             // 10 floats: 2^s
 static_assert(F2_CB_SCALE + 10 <= CONST_FLOATS, "const block");
 constexpr int64_t F2_PACKED_BYTES = (int64_t)CONST_BYTES + (int64_t)F2_SUBS * F2_SUB_BYTES;
+__host__ __device__ constexpr int f2_sigma(int q) { return (0x78 >> (2 * q)) & 3; }     // 0, 2, 3, 1
+__host__ __device__ constexpr int f2_frag_offset(int n, int g) { return n * 64 + ((g ^ f2_sigma((n >> 2) & 3)) << 4); }
 
 // physical byte offset, inside a chunk image, of the 16-byte slot holding
 // W[row n][k-group c] (c = (k % 32) / 4)

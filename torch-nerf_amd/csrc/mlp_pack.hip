@@ -156,15 +156,17 @@ __global__ void pack_bf16_kernel(const Params P, char *__restrict__ out) {
 // ---- split-f16 stream (mlp_layout.h "split-f16 inference stream")
 // pass 1, one block per matrix-pipe layer l = 0..9: s_l = 13 - floor(log2(max |W_l|)) (fc_8: rows 1..256 -- the density row
 // stays fp32 on the vector ALU), 2^-s and 2^s into the const block of the stream
-__global__ void f16x2_scale_kernel(const Params P, float *__restrict__ cblock) {
+__global__ __launch_bounds__(1024) void f16x2_scale_kernel(const Params P, float *__restrict__ cblock) {
     const int l = blockIdx.x;
-    const int rows = l == 8 ? FEAT : Net::layer_out(l), row0 = l == 8 ? 1 : 0, in = P.in[l];
-    __shared__ float red[256];
+    // the layer's weights are one contiguous run of the blob (fc_8: behind its first row)
+    const float *w = P.P + P.w_off[l] + (l == 8 ? P.in[8] : 0);
+    const int count = (l == 8 ? FEAT : Net::layer_out(l)) * P.in[l];
+    __shared__ float red[1024];
     float m = 0.0f;
-    for (int e = threadIdx.x; e < rows * in; e += blockDim.x) m = fmaxf(m, fabsf(P.w(l, row0 + e / in, e % in)));
+    for (int e = threadIdx.x; e < count; e += 1024) m = fmaxf(m, fabsf(w[e]));
     red[threadIdx.x] = m;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 512; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
         __syncthreads();
     }
@@ -221,7 +223,7 @@ __global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
         const int image = in_sub / image_bytes;                // 2 kbi + part (0 hi, 1 lo)
         const int b = in_sub % image_bytes;                    // byte offset inside the image
         const int n = b >> 6;                                  // row (64 B per row)
-        const int g = ((b & 63) >> 4) ^ ((n >> 2) & 3);        // logical fragment = lane group
+        const int g = ((b & 63) >> 4) ^ f2_sigma((n >> 2) & 3);   // logical fragment = lane group (f2_frag_offset)
         const int el = (b & 15) >> 1;
         const int kk = 16 * (el >> 2) + 4 * g + (el & 3);
         int layer;
@@ -271,7 +273,7 @@ NERF_API int nerf_mlp_pack_f16x2(const nerf_net_t *net, const float *params, voi
     Params P;
     if (int rc = nerf::fused_net(net, P.net, "nerf_mlp_pack_f16x2")) return rc;
     P.set(params);
-    hipLaunchKernelGGL(f16x2_scale_kernel, dim3(10), dim3(256), 0, nerf::as_stream(stream), P,
+    hipLaunchKernelGGL(f16x2_scale_kernel, dim3(10), dim3(1024), 0, nerf::as_stream(stream), P,
                        reinterpret_cast<float *>(packed));
     hipLaunchKernelGGL(pack_f16x2_kernel, dim3(1024), dim3(256), 0, nerf::as_stream(stream), P,
                        reinterpret_cast<char *>(packed));

@@ -42,9 +42,15 @@ class PrimitiveCube(PrimitiveBase):
 
     @property
     def fused_query(self) -> bool:
-        """True when query_points hands RAW points to ONE network kernel (no encoding tensor, no per-layer activations in
-        HBM on the inference path): the renderer then ignores `num_ray_batch`, which exists to bound those."""
-        return self.raw_net() is not None
+        """True when query_points hands RAW points to ONE network kernel AND keeps nothing per sample in HBM -- the
+        inference path (no gradients wanted): the renderer then ignores `num_ray_batch`, which exists to bound exactly
+        that.  A call that records for a backward pass allocates activation planes for every row it is given (10 - 20 KB
+        per sample), so there the caller's batching is honoured like in the reference (volume_renderer.py:229-254)."""
+        if self.raw_net() is None:
+            return False
+        net = self._radiance_field
+        recording = torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
+        return not recording
 
     def query_points(self, pos: torch.Tensor, view_dir: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """pos, view_dir (N,S,3) -> sigma (N,S), radiance (N,S,3)."""
