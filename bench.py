@@ -734,6 +734,22 @@ def configs_leg(nets, flats, device):
                         "max_abs_err_vs_fp32_frame": float((img16 - ref32).abs().max().item()),
                         "what": "Blender geometry 800x800, 64+128, bf16 weights + layer inputs on v_mfma_f32_32x32x16_bf16 "
                                 "(fp32 accumulate), whole frame on 1 GPU through shard.render_frame(bf16=True)"}
+    # ---- the same frame on the split-f16 kernel (round 6): the fp32 bound on the f16 matrix pipe
+    shard.render_frame(cam8, nets[0], nets[1], N_COARSE, N_FINE, False, seed=4, single_rank=True, f16x2=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    imgx = shard.render_frame(cam8, nets[0], nets[1], N_COARSE, N_FINE, False, seed=4, single_rank=True, f16x2=True)
+    torch.cuda.synchronize()
+    dtx = time.perf_counter() - t0
+    errx = (imgx - ref32).abs().max(dim=1).values
+    out["lego_f16x2"] = {"ms": dtx * 1e3, "rays_per_s": H * W / dtx, "rays": H * W, "dtype": "f16x2",
+                         "median_abs_err_vs_fp32_frame": float(errx.median().item()),
+                         "pixels_beyond_1e-5_of_fp32_frame": int((errx > 1e-5).sum().item()),
+                         "max_abs_err_vs_fp32_frame": float(errx.max().item()),
+                         "psnr_vs_fp32_frame_db": float(-10.0 * np.log10(max(torch.mean((imgx.double() - ref32.double()) ** 2).item(), 1e-20))),
+                         "what": "Blender geometry 800x800, 64+128, every MLP operand split in two f16 parts (three "
+                                 "v_mfma_f32_16x16x32_f16 per k-step, fp32 accumulate), whole frame on 1 GPU through "
+                                 "shard.render_frame(f16x2=True); pixels beyond 1e-5 = rays where a fine sample changed its cdf bin"}
     out["llff"] = {"ms": dt * 1e3, "rays_per_s": Hl * Wl / dt, "rays": Hl * Wl, "finite": bool(torch.isfinite(img).all()),
                    "image_sha256_16": hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()[:16],
                    "what": "LLFF fern geometry 1008x756, NDC rays, t in [0,1], 64+128, fp32, 1 GPU, full frame"}

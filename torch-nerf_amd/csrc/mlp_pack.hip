@@ -154,32 +154,46 @@ __global__ void pack_bf16_kernel(const Params P, char *__restrict__ out) {
 
 
 // ---- split-f16 stream (mlp_layout.h "split-f16 inference stream")
-// pass 1, one block per matrix-pipe layer l = 0..9: s_l = 13 - floor(log2(max |W_l|)) (fc_8: rows 1..256 -- the density row
-// stays fp32 on the vector ALU), 2^-s and 2^s into the const block of the stream
-__global__ __launch_bounds__(1024) void f16x2_scale_kernel(const Params P, float *__restrict__ cblock) {
-    const int l = blockIdx.x;
+// The per-layer scale 2^s, s = 13 - floor(log2(max |W_l|)) (fc_8: rows 1..256 -- the density row stays fp32 on the vector
+// ALU), in two steps because the stream is re-packed on EVERY call of the module (NeRF._stream_f16x2) and one block per
+// layer walking 81 k weights cost 16 us of a 2.9 ms render step: F2_SLICES blocks per layer leave partial maxima in the
+// const block's spare floats, and every block of the pack kernel folds the 160 partials into its own copy of the scales.
+constexpr int F2_SLICES = 16;
+constexpr int F2_CB_PARTIAL = F2_CB_SCALE + 10;     // 10 x F2_SLICES floats
+static_assert(F2_CB_PARTIAL + 10 * F2_SLICES <= CONST_FLOATS, "const block");
+
+__global__ __launch_bounds__(256) void f16x2_absmax_kernel(const Params P, float *__restrict__ cblock) {
+    const int l = blockIdx.y, slice = blockIdx.x;
     // the layer's weights are one contiguous run of the blob (fc_8: behind its first row)
     const float *w = P.P + P.w_off[l] + (l == 8 ? P.in[8] : 0);
     const int count = (l == 8 ? FEAT : Net::layer_out(l)) * P.in[l];
-    __shared__ float red[1024];
+    const int per = (count + F2_SLICES - 1) / F2_SLICES, lo = slice * per, hi = lo + per < count ? lo + per : count;
+    __shared__ float red[256];
     float m = 0.0f;
-    for (int e = threadIdx.x; e < count; e += 1024) m = fmaxf(m, fabsf(w[e]));
+    for (int e = lo + threadIdx.x; e < hi; e += 256) m = fmaxf(m, fabsf(w[e]));
     red[threadIdx.x] = m;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const float mx = red[0];
+    if (threadIdx.x == 0) cblock[F2_CB_PARTIAL + l * F2_SLICES + slice] = red[0];
+}
+
+// scale[l] = 2^s, unscale[l] = 2^-s from the partial maxima (every thread of the block calls this; shared arrays of 10)
+__device__ __forceinline__ void f16x2_scales(const float *cblock, float *scale, float *unscale) {
+    if (threadIdx.x < 10) {
+        float mx = 0.0f;
+        for (int k = 0; k < F2_SLICES; ++k) mx = fmaxf(mx, cblock[F2_CB_PARTIAL + threadIdx.x * F2_SLICES + k]);
         int s = 0;
         if (mx > 0.0f && mx < INFINITY) {
             s = 13 - ilogbf(mx);
             s = s > 40 ? 40 : (s < -40 ? -40 : s);     // (all-tiny or huge layers: keep 2^s and the scaled biases finite)
         }
-        cblock[F2_CB_UNSCALE + l] = ldexpf(1.0f, -s);
-        cblock[F2_CB_SCALE + l] = ldexpf(1.0f, s);
+        scale[threadIdx.x] = ldexpf(1.0f, s);
+        unscale[threadIdx.x] = ldexpf(1.0f, -s);
     }
+    __syncthreads();
 }
 
 // (layer, output row offset, k) of stream position (sub, kbi = k-block inside the sub-step, kk); k < 0: zero filler
@@ -202,17 +216,24 @@ __device__ float f16x2_stream_value(const Params &P, int sub, int kbi, int n, in
 
 __global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
     float *cblock = reinterpret_cast<float *>(out);
+    __shared__ float scale[10], unscale[10];
+    f16x2_scales(cblock, scale, unscale);
     _Float16 *stream = reinterpret_cast<_Float16 *>(out + CONST_BYTES);
     const int64_t n_f16 = (int64_t)F2_SUBS * F2_SUB_BYTES / 2;
     const int64_t total = CONST_FLOATS + n_f16;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         if (e < CONST_FLOATS) {
-            if (e >= F2_CB_UNSCALE && e < F2_CB_SCALE + 10) continue;          // written by f16x2_scale_kernel
-            float v = const_block_value(P, (int)e);
-            if (e < CB_BIAS8) v *= cblock[F2_CB_SCALE + e / 256];             // biases ride in the scaled accumulators
-            else if (e < CB_BIAS9) v *= cblock[F2_CB_SCALE + 8];
-            else if (e < CB_W8ROW0) v *= cblock[F2_CB_SCALE + 9];
+            if (e >= F2_CB_PARTIAL) continue;                                  // the absmax kernel's partials (and padding)
+            float v;
+            if (e >= F2_CB_SCALE) v = scale[e - F2_CB_SCALE];
+            else if (e >= F2_CB_UNSCALE) v = unscale[e - F2_CB_UNSCALE];
+            else {
+                v = const_block_value(P, (int)e);
+                if (e < CB_BIAS8) v *= scale[e / 256];                         // biases ride in the scaled accumulators
+                else if (e < CB_BIAS9) v *= scale[8];
+                else if (e < CB_W8ROW0) v *= scale[9];
+            }
             cblock[e] = v;
             continue;
         }
@@ -227,7 +248,7 @@ __global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
         const int el = (b & 15) >> 1;
         const int kk = 16 * (el >> 2) + 4 * g + (el & 3);
         int layer;
-        const float w = f16x2_stream_value(P, sub, image >> 1, n, kk, layer) * cblock[F2_CB_SCALE + layer];
+        const float w = f16x2_stream_value(P, sub, image >> 1, n, kk, layer) * scale[layer];
         const _Float16 hi = (_Float16)w;
         stream[r] = (image & 1) ? (_Float16)(w - (float)hi) : hi;
     }
@@ -273,7 +294,7 @@ NERF_API int nerf_mlp_pack_f16x2(const nerf_net_t *net, const float *params, voi
     Params P;
     if (int rc = nerf::fused_net(net, P.net, "nerf_mlp_pack_f16x2")) return rc;
     P.set(params);
-    hipLaunchKernelGGL(f16x2_scale_kernel, dim3(10), dim3(1024), 0, nerf::as_stream(stream), P,
+    hipLaunchKernelGGL(f16x2_absmax_kernel, dim3(F2_SLICES, 10), dim3(256), 0, nerf::as_stream(stream), P,
                        reinterpret_cast<float *>(packed));
     hipLaunchKernelGGL(pack_f16x2_kernel, dim3(1024), dim3(256), 0, nerf::as_stream(stream), P,
                        reinterpret_cast<char *>(packed));
