@@ -343,6 +343,10 @@ def cpu_baseline(flats, focal, pose, device):
     psnr = float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)
     base = {"value": n / secs, "unit": "rays/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "cpus_visible": os.cpu_count(),
+            # how the port compares with the reference it stands in for (the reference cannot travel to this box):
+            # scripts/port_vs_reference.py, build container, alternating passes -> profiles/r06_port_vs_reference.json
+            "port_vs_reference": "1.00x (0.99 - 1.00) of the imported reference's rays/s on the build container: 1024 rays, "
+                                 "8 threads, 7 alternating passes each, medians 727 vs 729 rays/s",
             "sample": f"{n} of the 4096 rays of one batch, coarse 64 + fine 64+128, forward, eager PyTorch CPU "
                       f"port of the reference path (oracle/torch_port.py), {cores} threads, {secs:.1f} s per pass"}
     quality = {"psnr_vs_cpu_port_db": (None if psnr == float("inf") else round(psnr, 2)),

@@ -129,6 +129,9 @@ def test_entry_points_refuse_what_they_cannot_serve_before_touching_the_gpu():
     assert lib.nerf_mlp_forward_f16x2(sh, p, p, p, 4, p, p, None) == UNSUPPORTED and b"levels" in lib.nerf_amd_last_error()
     assert lib.nerf_mlp_forward_f16x2(f128, p, p, p, 4, p, p, None) == UNSUPPORTED
     assert lib.nerf_mlp_packed_f16x2_bytes(f128) == -1 and lib.nerf_mlp_packed_f16x2_bytes(other) == 13312 + 73 * 32768
+    wide = net(75, 33, 256, 12, 1, 5, 1)                                            # three position + two direction k-blocks
+    assert lib.nerf_mlp_packed_f16x2_bytes(wide) == 13312 + (2 * 3 + 64 + 5) * 32768
+    assert lib.nerf_mlp_packed_f16x2_bytes(net(129, 27, 256, -1, 0, -1, 0)) == -1 and b"split-f16" in lib.nerf_amd_last_error()
     assert lib.nerf_mlp_pack_f16x2(None, None, None, None) == ARG
     assert lib.nerf_mlp_forward_f16x2(None, p, p, p, 0, p, p, None) == OK and lib.nerf_mlp_forward_f16x2(None, p, p, p, -1, p, p, None) == ARG
     bad = net(63, 27, 256, 9, 1, 4, 1)

@@ -234,3 +234,69 @@ def test_sharded_frame_on_the_split_kernel_equals_the_fp32_frame_to_the_bound():
     assert torch.equal(b, c)
     err = (a - b).abs().max(dim=1).values
     assert float((err > ATOL).float().mean()) <= 5e-3 and float(err.median()) <= 1e-6
+
+
+WIDE = {   # yaml values beyond the fused family (runner_utils.py:584-612): (coord_encode_level, dir_encode_level, include_input)
+    "coord_l12": (12, 4, True),            # NeRF(75, 27): three position k-blocks
+    "dir_l5": (10, 5, True),               # NeRF(63, 33): two direction k-blocks
+    "coord_l12_dir_l6": (12, 6, True),     # NeRF(75, 39)
+    "coord_l20_dir_l10": (20, 10, True),   # NeRF(123, 63): four + two, the widest the kernel takes
+    "coord_l16_noinput": (16, 4, False),   # NeRF(96, 24): exactly three blocks, no raw coordinates
+}
+
+
+@pytest.mark.parametrize("tag", sorted(WIDE))
+def test_wider_encoders_against_the_oracle(oracle, tag):
+    """The split kernel's NPOS / NDIR instantiations: outputs at the fp32 bound against the C oracle, through the raw entry
+    and through PrimitiveCube.query_points with NeRF.f16x2_inference (the layered family's networks take this kernel for
+    no-grad queries), ragged M."""
+    lp, ld, inc = WIDE[tag]
+    ce, de = PositionalEncoder(3, lp, inc), PositionalEncoder(3, ld, inc)
+    rng = np.random.RandomState(lp * 16 + ld)
+    M = 2999
+    pts = rng.uniform(-1.5, 1.5, (M, 3)).astype(np.float32)      # (2^19 x stays inside the fast sincos range)
+    dirs = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    flat = synth.nerf_flat_params(seed=7, pos_dim=ce.out_dim, view_dir_dim=de.out_dim, sigma_bias=0.5, sigma_gain=8.0)
+    so, co = oracle.mlp_forward(flat, oracle.posenc(pts, lp, inc), oracle.posenc(dirs, ld, inc))
+    spec = ops.Net(ce.out_dim, de.out_dim, 256, lp, inc, ld, inc)
+    assert spec.f16x2_ok and not spec.fused
+    s, c = ops.mlp_forward_f16x2(ops.mlp_pack_f16x2(dev(flat), spec), dev(pts), dev(dirs), spec)
+    close(c, co, GOLDEN_ATOL)
+    assert (np.abs(s.cpu().numpy() - so) / np.maximum(np.abs(so), 1.0)).max() <= GOLDEN_ATOL
+    net = network.NeRF(ce.out_dim, de.out_dim)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in
+                         synth.split_flat_params(flat, ce.out_dim, de.out_dim, 256).items()})
+    cube = scene.PrimitiveCube(net.cuda(), {"coord_enc": ce, "dir_enc": de})
+    net.f16x2_inference = True
+    with torch.no_grad():
+        s2, c2 = cube.query_points(dev(pts).view(M, 1, 3), dev(dirs).view(M, 1, 3))
+    assert torch.equal(s2.view(-1), s) and torch.equal(c2.view(M, 3), c)
+    s3, _ = cube.query_points(dev(pts).view(M, 1, 3), dev(dirs).view(M, 1, 3))      # gradients wanted: the fp32 record kernels
+    assert s3.requires_grad and float((s3.detach().view(-1) - s).abs().max()) <= 1e-4
+
+
+def test_sharded_frame_of_a_wide_encoder_scene_on_the_split_kernel():
+    """shard.render_frame(f16x2=True) on scenes outside the fused family: the kernel chain with the split kernel inside
+    (flags set for the call and restored), launch-granularity independent, within the bound of the fp32 chain."""
+    H, W = 40, 56
+    cam = cameras.PerspectiveCamera({"f_x": 60.0, "f_y": 60.0, "img_width": W, "img_height": H},
+                                    torch.from_numpy(synth.pose_spherical(10.0, -30.0, 4.0)), 2.0, 6.0)
+    ce, de = PositionalEncoder(3, 12, True), PositionalEncoder(3, 5, True)
+    scenes = []
+    for seed in (3, 4):
+        flat = synth.nerf_flat_params(seed=seed, pos_dim=ce.out_dim, view_dir_dim=de.out_dim, sigma_bias=1.0, sigma_gain=8.0)
+        net = network.NeRF(ce.out_dim, de.out_dim)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in
+                             synth.split_flat_params(flat, ce.out_dim, de.out_dim, 256).items()})
+        scenes.append(scene.PrimitiveCube(net.cuda(), {"coord_enc": ce, "dir_enc": de}))
+    a = shard.render_frame(cam, scenes[0], scenes[1], 64, 128, False, seed=5, single_rank=True)
+    b = shard.render_frame(cam, scenes[0], scenes[1], 64, 128, False, seed=5, single_rank=True, f16x2=True)
+    c = shard.render_frame(cam, scenes[0], scenes[1], 64, 128, False, seed=5, single_rank=True, f16x2=True, rays_per_launch=700)
+    assert torch.equal(b, c) and not torch.equal(a, b)
+    assert not scenes[0].radiance_field.f16x2_inference and not scenes[1].radiance_field.f16x2_inference
+    err = (a - b).abs().max(dim=1).values
+    assert float((err > ATOL).float().mean()) <= 5e-3 and float(err.median()) <= 1e-6
+    sh = scene.PrimitiveCube(network.NeRF(16, 16).cuda(), None)
+    with pytest.raises(RuntimeError, match="split-f16"):
+        shard.render_frame(cam, sh, sh, 64, 128, False, seed=5, single_rank=True, f16x2=True)

@@ -22,7 +22,8 @@
 //   * encodings in fp32 (one accurate sincos per needed feature, the library path for huge arguments, like the fp32
 //     kernels), split like every other activation; biases ride pre-scaled in the C fragment; the density row of fc_8
 //     (from the unsplit fp32 h7), fc_out and the sigmoid stay fp32 on the vector ALU
-// Every network of the fused family behind two PositionalEncoders (run-time levels / include_input).  Inference only.
+// Every NeRF(pos_dim <= 128, view_dir_dim <= 64, 256) behind two PositionalEncoders (run-time levels / include_input): the
+// fused family and the wider inputs of coord_encode_level 11..20 / dir_encode_level 5..10.  Inference only.
 // Range: an input, encoding or activation beyond +-65504 cannot be split; the kernel tracks the largest magnitude it
 // splits per sample and returns NaN for such a sample (never a silent wrong value).
 #include <type_traits>
@@ -42,7 +43,6 @@ constexpr int WSAMPLES = 16;                     // samples per wavefront (the N
 constexpr int TILE = WSAMPLES * WAVES;           // samples per workgroup pass
 constexpr int SUB_BYTES = F2_SUB_BYTES;
 constexpr int RING = 4;
-constexpr int SUBS_PER_TILE = F2_SUBS;
 constexpr int PIECES = SUB_BYTES / 1024 / WAVES; // 1-KiB DMA pieces per wave per sub-step
 constexpr int F2_LDS_BYTES = RING * SUB_BYTES + CONST_BYTES;
 static_assert(PIECES == 4, "ring geometry");
@@ -53,8 +53,9 @@ struct SubPipe {
     unsigned lane_off;     // lane * 16
     unsigned lds_wave;     // LDS address of ring slot 0 + wave * 4 KiB
     unsigned issued;       // sub-steps requested so far (ring slot = issued % RING)
-    int issue_q;           // position in the tile, [0, SUBS_PER_TILE), of the next sub-step to request
+    int issue_q;           // position in the tile, [0, subs_per_tile), of the next sub-step to request
     unsigned consumed;     // sub-steps this wave has consumed
+    int subs_per_tile;     // F2Layout::subs() of the network
 
     __device__ __forceinline__ void issue_piece(int p) const {
         lds_dma_16s(src_wave + issue_q * SUB_BYTES + p * 1024, lane_off,
@@ -62,7 +63,7 @@ struct SubPipe {
     }
     __device__ __forceinline__ void issue_done() {
         ++issued;
-        issue_q = (issue_q + 1 == SUBS_PER_TILE) ? 0 : issue_q + 1;
+        issue_q = (issue_q + 1 == subs_per_tile) ? 0 : issue_q + 1;
     }
     __device__ __forceinline__ void rendezvous() {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PIECES) : "memory");
@@ -188,6 +189,9 @@ __device__ __forceinline__ void encode_split(float x, float y, float z, int g, i
         }
 }
 
+// NPOS (2 | 3 | 4) position k-blocks, NDIR (1 | 2) direction k-blocks: <2, 1> is the fused family (the shipped 63 / 27 and
+// every coord_encode_level <= 10 / dir_encode_level <= 4); the others serve the wider encoders the yaml can name
+template <int NPOS, int NDIR>
 __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const Net net, const char *__restrict__ packed,
                                                                            const float *__restrict__ pos,
                                                                            const float *__restrict__ dir, int64_t M,
@@ -214,6 +218,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
     pipe.issued = 0;
     pipe.issue_q = 0;
     pipe.consumed = 0;
+    pipe.subs_per_tile = F2Layout{NPOS, NDIR}.subs();
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 2; ++q) {   // sub-steps 0 and 1 are in flight before the first rendezvous
@@ -247,8 +252,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
 
         f32x4 acc[16];                 // [16-feature output block]
         f16x8 act_hi[8], act_lo[8];    // [32-feature input block]
-        f16x8 pe_hi[2], pe_lo[2];      // the encoded position: fc_in and the fc_5 skip connection
-        f16x8 de_hi[1], de_lo[1];      // the encoded direction (fc_9): evaluated up front too, while nothing else is live
+        f16x8 pe_hi[NPOS], pe_lo[NPOS];   // the encoded position: fc_in and the fc_5 skip connection
+        f16x8 de_hi[NDIR], de_lo[NDIR];   // the encoded direction (fc_9): evaluated up front too, while nothing else is live
         float sigma_pre = 0.0f;
         float amax = 0.0f;             // largest magnitude split so far (f16 range check, see split4)
         // (the lane group as a value hipcc cannot reason about: the feature-index arithmetic of the encodings would
@@ -314,15 +319,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
 
         // ---- fc_in (nerf.py:102): sub-steps 0, 1
         if (exact) {
-            encode_split<2, true>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo, amax);
-            encode_split<1, true>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo, amax);
+            encode_split<NPOS, true>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo, amax);
+            encode_split<NDIR, true>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo, amax);
         } else {
-            encode_split<2, false>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo, amax);
-            encode_split<1, false>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo, amax);
+            encode_split<NPOS, false>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo, amax);
+            encode_split<NDIR, false>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo, amax);
         }
         load_bias_blocks(cb_ + CB_BIAS, 0, 16);
-        sub_step(pe_hi[0], pe_lo[0]);
-        sub_step(pe_hi[1], pe_lo[1]);
+#pragma unroll
+        for (int kb = 0; kb < NPOS; ++kb) sub_step(pe_hi[kb], pe_lo[kb]);
         // ---- fc_1 .. fc_4 (:103-106)
         for (int l = 1; l <= 4; ++l) plain_layer(l - 1, No(), cb_ + CB_BIAS + l * 256);
         // ---- fc_5 on cat([pos, x]) (:108): position FIRST
@@ -332,7 +337,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
             seam_half(Second(), Yes(), No(), Full(), 4, cb_ + CB_BIAS + 5 * 256);
             mma_kblock<16, PIECES, 0, F2_IMAGE_BYTES>(acc, pe_hi[0], pe_lo[0], a, pipe);
             pipe.issue_done();
-            sub_step(pe_hi[1], pe_lo[1]);
+#pragma unroll
+            for (int kb = 1; kb < NPOS; ++kb) sub_step(pe_hi[kb], pe_lo[kb]);
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) sub_step(act_hi[kb], act_lo[kb]);
         }
@@ -357,7 +363,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
                 pipe.issue_done();
             }
             a = frag + pipe.acquire();
-            mma_kblock<8, PIECES, 0, F2_IMAGE_BYTES / 2>(acc, de_hi[0], de_lo[0], a, pipe);     // (+ a zero k-block: skipped)
+            mma_kblock<8, PIECES, 0, F2_IMAGE_BYTES / 2>(acc, de_hi[0], de_lo[0], a, pipe);     // (NDIR = 1: + a zero k-block, skipped)
+            if (NDIR > 1) mma_kblock<8, 0, F2_IMAGE_BYTES, 3 * F2_IMAGE_BYTES / 2>(acc, de_hi[NDIR - 1], de_lo[NDIR - 1], a, pipe);
             pipe.issue_done();
         }
 
@@ -406,20 +413,26 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
 NERF_API int nerf_mlp_forward_f16x2(const nerf_net_t *net_abi, const void *packed_f16x2, const float *pos,
                                     const float *view_dir, int64_t M, float *sigma, float *rgb, nerf_stream_t stream) {
     mlp::Net net;
-    if (int rc = nerf::fused_net(net_abi, net, "nerf_mlp_forward_f16x2")) return rc;
+    if (int rc = nerf::f16x2_net(net_abi, net, "nerf_mlp_forward_f16x2")) return rc;
     if (!nerf::raw_inputs_ok(net))
         return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_mlp_forward_f16x2: the kernel encodes raw points: nerf_net_t needs the "
                                                 "levels of both PositionalEncoders");
     NERF_REQUIRE(M >= 0, "nerf_mlp_forward_f16x2: negative M");
     if (M == 0) return NERF_OK;
     NERF_REQUIRE(packed_f16x2 && pos && view_dir && sigma && rgb, "nerf_mlp_forward_f16x2: null pointer");
-    static nerf::DeviceMask configured = {0};
-    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_forward_f16x2_kernel), F2_LDS_BYTES, configured,
+    const mlp::F2Layout L = mlp::f2_layout(net.e_pos, net.e_dir);
+    typedef void (*Kernel)(const Net, const char *, const float *, const float *, int64_t, float *, float *);
+    static const Kernel kernels[3][2] = {{mlp_forward_f16x2_kernel<2, 1>, mlp_forward_f16x2_kernel<2, 2>},
+                                         {mlp_forward_f16x2_kernel<3, 1>, mlp_forward_f16x2_kernel<3, 2>},
+                                         {mlp_forward_f16x2_kernel<4, 1>, mlp_forward_f16x2_kernel<4, 2>}};
+    static nerf::DeviceMask configured[3][2] = {{{0}, {0}}, {{0}, {0}}, {{0}, {0}}};
+    const Kernel kern = kernels[L.npos - 2][L.ndir - 1];
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), F2_LDS_BYTES, configured[L.npos - 2][L.ndir - 1],
                                           "nerf_mlp_forward_f16x2: LDS attribute"))
         return rc;
     const int cus = nerf::device_cus();
     const int64_t ntiles = (M + TILE - 1) / TILE;
-    hipLaunchKernelGGL(mlp_forward_f16x2_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(64 * WAVES), F2_LDS_BYTES,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(64 * WAVES), F2_LDS_BYTES,
                        nerf::as_stream(stream), net, static_cast<const char *>(packed_f16x2), pos, view_dir, M, sigma, rgb);
     return nerf::check_launch("nerf_mlp_forward_f16x2");
 }

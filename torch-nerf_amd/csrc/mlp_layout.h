@@ -204,6 +204,7 @@ __host__ __device__ constexpr int b16_frag_offset(int n, int slot) { return n * 
 //     banks (PMC: 48 % of the LDS-active cycles were bank conflicts, profiles/r06_pmc_f16x2_first_cut.txt);
 //     scripts/lds_b128_probe.hip times all 24 sigma.
 //   fc_9 (128 rows): images of 8 KiB, TWO k-blocks per sub-step: [hi kb][lo kb][hi kb+1][lo kb+1]
+//   (the shipped 63 / 27: two position k-blocks, one direction k-block; F2Layout below for the wider inputs)
 //   subs 0,1      fc_in  (encoded position, two k-blocks)         subs 44..59   fc_6, fc_7
 //   subs 2..33    fc_1 .. fc_4  (8 per layer)                     subs 60..67   fc_8 rows 1..256
 //   subs 34,35    fc_5[:, 0:E_p]  (skip connection, pos first)    subs 68..71   fc_9[:, 0:256], two k-blocks each
@@ -212,12 +213,31 @@ __host__ __device__ constexpr int b16_frag_offset(int n, int slot) { return n * 
 // plus the ten factors 2^-s (layers fc_in .. fc_9) the seams multiply the accumulators with, and 2^s for the packer.
 constexpr int F2_IMAGE_BYTES = CHUNK_ROWS * CHUNK_K * 2;    // 16 KiB
 constexpr int F2_SUB_BYTES = 2 * F2_IMAGE_BYTES;            // 32 KiB
-constexpr int F2_SUBS = 73;
-constexpr int F2_SUB_FC5_POS = 34, F2_SUB_FC5 = 36, F2_SUB_FC6 = 44, F2_SUB_FC8 = 60, F2_SUB_FC9 = 68;
+// The split kernel also serves the wider inputs the yaml can name (coord_encode_level 11..20 -> pos_dim <= 123,
+// dir_encode_level 5..10 -> view_dir_dim <= 63, runner_utils.py:584-612): NPOS = 2 | 3 | 4 position k-blocks (at least the
+// fused family's two) and NDIR = 1 | 2 direction k-blocks, with feat_dim 256.  Sub-steps in consumption order:
+//   fc_in NPOS | fc_1..fc_4 32 | fc_5 position NPOS | fc_5 8 | fc_6, fc_7 16 | fc_8 8 | fc_9 ceil((8 + NDIR) / 2)
+constexpr int F2_MAX_E_POS = 128, F2_MAX_E_DIR = 64;
+struct F2Layout {
+    int npos, ndir;
+    __host__ __device__ constexpr int sub_fc1() const { return npos; }
+    __host__ __device__ constexpr int sub_fc5_pos() const { return npos + 32; }
+    __host__ __device__ constexpr int sub_fc5() const { return 2 * npos + 32; }
+    __host__ __device__ constexpr int sub_fc6() const { return 2 * npos + 40; }
+    __host__ __device__ constexpr int sub_fc8() const { return 2 * npos + 56; }
+    __host__ __device__ constexpr int sub_fc9() const { return 2 * npos + 64; }
+    __host__ __device__ constexpr int subs() const { return 2 * npos + 64 + (8 + ndir + 1) / 2; }
+    __host__ __device__ constexpr int64_t packed_bytes() const { return (int64_t)CONST_BYTES + (int64_t)subs() * F2_SUB_BYTES; }
+};
+__host__ __device__ constexpr F2Layout f2_layout(int e_pos, int e_dir) {
+    return F2Layout{e_pos <= 64 ? 2 : (e_pos + 31) / 32, (e_dir + 31) / 32};
+}
+constexpr int F2_SUBS = f2_layout(63, 27).subs();           // 73: the shipped network
+static_assert(F2_SUBS == 73, "split-f16 stream of NeRF(63, 27, 256)");
 constexpr int F2_CB_UNSCALE = CB_SCALARS + 4;               // 10 floats: 2^-s of fc_in .. fc_9
 constexpr int F2_CB_SCALE = F2_CB_UNSCALE + 10;             // 10 floats: 2^s
 static_assert(F2_CB_SCALE + 10 <= CONST_FLOATS, "const block");
-constexpr int64_t F2_PACKED_BYTES = (int64_t)CONST_BYTES + (int64_t)F2_SUBS * F2_SUB_BYTES;
+constexpr int64_t F2_PACKED_BYTES = f2_layout(63, 27).packed_bytes();
 __host__ __device__ constexpr int f2_sigma(int q) { return (0x78 >> (2 * q)) & 3; }     // 0, 2, 3, 1
 __host__ __device__ constexpr int f2_frag_offset(int n, int g) { return n * 64 + ((g ^ f2_sigma((n >> 2) & 3)) << 4); }
 

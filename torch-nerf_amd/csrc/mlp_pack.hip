@@ -196,22 +196,24 @@ __device__ __forceinline__ void f16x2_scales(const float *cblock, float *scale, 
     __syncthreads();
 }
 
-// (layer, output row offset, k) of stream position (sub, kbi = k-block inside the sub-step, kk); k < 0: zero filler
-__device__ float f16x2_stream_value(const Params &P, int sub, int kbi, int n, int kk, int &layer) {
+// weight value of stream position (sub, kbi = k-block inside the sub-step, row n, kk) and its layer; zero filler where the
+// (padded) k-block has no input feature
+__device__ float f16x2_stream_value(const Params &P, const F2Layout &L, int sub, int kbi, int n, int kk, int &layer) {
     const int E_POS = P.net.e_pos, E_DIR = P.net.e_dir;
-    if (sub < 2 || (sub >= F2_SUB_FC5_POS && sub < F2_SUB_FC5)) {     // encoded position into fc_in / fc_5 (pos first)
-        layer = sub < 2 ? 0 : 5;
-        const int k = 32 * (sub < 2 ? sub : sub - F2_SUB_FC5_POS) + kk;
+    if (sub < L.sub_fc1() || (sub >= L.sub_fc5_pos() && sub < L.sub_fc5())) {   // encoded position into fc_in / fc_5 (pos first)
+        layer = sub < L.sub_fc1() ? 0 : 5;
+        const int k = 32 * (sub < L.sub_fc1() ? sub : sub - L.sub_fc5_pos()) + kk;
         return k < E_POS ? P.w(layer, n, k) : 0.0f;
     }
-    if (sub < F2_SUB_FC5_POS) { layer = 1 + (sub - 2) / 8; return P.w(layer, n, 32 * ((sub - 2) % 8) + kk); }
-    if (sub < F2_SUB_FC6) { layer = 5; return P.w(5, n, E_POS + 32 * (sub - F2_SUB_FC5) + kk); }
-    if (sub < F2_SUB_FC8) { layer = 6 + (sub - F2_SUB_FC6) / 8; return P.w(layer, n, 32 * ((sub - F2_SUB_FC6) % 8) + kk); }
-    if (sub < F2_SUB_FC9) { layer = 8; return P.w(8, n + 1, 32 * (sub - F2_SUB_FC8) + kk); }
+    if (sub < L.sub_fc5_pos()) { layer = 1 + (sub - L.sub_fc1()) / 8; return P.w(layer, n, 32 * ((sub - L.sub_fc1()) % 8) + kk); }
+    if (sub < L.sub_fc6()) { layer = 5; return P.w(5, n, E_POS + 32 * (sub - L.sub_fc5()) + kk); }
+    if (sub < L.sub_fc8()) { layer = 6 + (sub - L.sub_fc6()) / 8; return P.w(layer, n, 32 * ((sub - L.sub_fc6()) % 8) + kk); }
+    if (sub < L.sub_fc9()) { layer = 8; return P.w(8, n + 1, 32 * (sub - L.sub_fc8()) + kk); }
     layer = 9;
-    const int ck = 2 * (sub - F2_SUB_FC9) + kbi;                      // k-block of fc_9; 8 = direction, 9 = filler
+    const int ck = 2 * (sub - L.sub_fc9()) + kbi;                     // k-block of fc_9; 8 .. 8 + NDIR - 1 = direction, then filler
     if (ck < 8) return P.w(9, n, 32 * ck + kk);
-    return (ck == 8 && kk < E_DIR) ? P.w(9, n, FEAT + kk) : 0.0f;
+    const int k = 32 * (ck - 8) + kk;
+    return k < E_DIR ? P.w(9, n, FEAT + k) : 0.0f;
 }
 
 __global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
@@ -219,7 +221,8 @@ __global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
     __shared__ float scale[10], unscale[10];
     f16x2_scales(cblock, scale, unscale);
     _Float16 *stream = reinterpret_cast<_Float16 *>(out + CONST_BYTES);
-    const int64_t n_f16 = (int64_t)F2_SUBS * F2_SUB_BYTES / 2;
+    const F2Layout L = f2_layout(P.net.e_pos, P.net.e_dir);
+    const int64_t n_f16 = (int64_t)L.subs() * F2_SUB_BYTES / 2;
     const int64_t total = CONST_FLOATS + n_f16;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
@@ -240,7 +243,7 @@ __global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
         const int64_t r = e - CONST_FLOATS;                    // f16 element index in the stream
         const int sub = (int)(r / (F2_SUB_BYTES / 2));
         const int in_sub = (int)(r % (F2_SUB_BYTES / 2)) * 2;  // byte offset inside the sub-step
-        const int image_bytes = sub >= F2_SUB_FC9 ? F2_IMAGE_BYTES / 2 : F2_IMAGE_BYTES;
+        const int image_bytes = sub >= L.sub_fc9() ? F2_IMAGE_BYTES / 2 : F2_IMAGE_BYTES;
         const int image = in_sub / image_bytes;                // 2 kbi + part (0 hi, 1 lo)
         const int b = in_sub % image_bytes;                    // byte offset inside the image
         const int n = b >> 6;                                  // row (64 B per row)
@@ -248,7 +251,7 @@ __global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
         const int el = (b & 15) >> 1;
         const int kk = 16 * (el >> 2) + 4 * g + (el & 3);
         int layer;
-        const float w = f16x2_stream_value(P, sub, image >> 1, n, kk, layer) * scale[layer];
+        const float w = f16x2_stream_value(P, L, sub, image >> 1, n, kk, layer) * scale[layer];
         const _Float16 hi = (_Float16)w;
         stream[r] = (image & 1) ? (_Float16)(w - (float)hi) : hi;
     }
@@ -286,13 +289,13 @@ NERF_API int nerf_mlp_pack_bf16(const nerf_net_t *net, const float *params, void
 
 NERF_API int64_t nerf_mlp_packed_f16x2_bytes(const nerf_net_t *net) {
     mlp::Net n;
-    return nerf::fused_net(net, n, "nerf_mlp_packed_f16x2_bytes") == NERF_OK ? mlp::F2_PACKED_BYTES : -1;
+    return nerf::f16x2_net(net, n, "nerf_mlp_packed_f16x2_bytes") == NERF_OK ? mlp::f2_layout(n.e_pos, n.e_dir).packed_bytes() : -1;
 }
 
 NERF_API int nerf_mlp_pack_f16x2(const nerf_net_t *net, const float *params, void *packed, nerf_stream_t stream) {
     NERF_REQUIRE(params && packed, "nerf_mlp_pack_f16x2: null pointer");
     Params P;
-    if (int rc = nerf::fused_net(net, P.net, "nerf_mlp_pack_f16x2")) return rc;
+    if (int rc = nerf::f16x2_net(net, P.net, "nerf_mlp_pack_f16x2")) return rc;
     P.set(params);
     hipLaunchKernelGGL(f16x2_absmax_kernel, dim3(F2_SLICES, 10), dim3(256), 0, nerf::as_stream(stream), P,
                        reinterpret_cast<float *>(packed));

@@ -42,4 +42,20 @@ inline int fused_net(const nerf_net_t *abi, mlp::Net &net, const char *who) {
 
 inline bool raw_inputs_ok(const mlp::Net &net) { return net.l_pos >= 0 && net.l_dir >= 0; }
 
+// For the split-f16 entries: feat_dim 256 with up to four position and two direction k-blocks (the fused family and the
+// wider inputs of coord_encode_level <= 20 / dir_encode_level <= 10).
+inline int f16x2_net(const nerf_net_t *abi, mlp::Net &net, const char *who) {
+    nerf_net_t d;
+    if (net_describe(abi, d) < 0) return NERF_ERR_ARG;
+    if (d.feat_dim != mlp::FEAT || d.pos_dim > mlp::F2_MAX_E_POS || d.view_dir_dim > mlp::F2_MAX_E_DIR) {
+        snprintf(error_buffer(), 256, "%s: NeRF(%d, %d, %d) is outside the split-f16 kernel (feat_dim 256, pos_dim <= 128, "
+                 "view_dir_dim <= 64)", who, d.pos_dim, d.view_dir_dim, d.feat_dim);
+        return NERF_ERR_UNSUPPORTED;
+    }
+    net.e_pos = d.pos_dim; net.e_dir = d.view_dir_dim;
+    net.l_pos = d.pos_levels; net.l_dir = d.dir_levels;
+    net.inc_pos = d.pos_include_input ? 1 : 0; net.inc_dir = d.dir_include_input ? 1 : 0;
+    return NERF_OK;
+}
+
 }  // namespace nerf

@@ -250,8 +250,9 @@ class Net:
     @property
     def f16x2_ok(self) -> bool:
         """True if the split-f16 inference kernel (fp32-grade results on the f16 matrix pipe, csrc/mlp_forward_f16x2.hip)
-        serves this network: the fused family behind two PositionalEncoders."""
-        return self.fused and self.knows_encoders
+        serves this network: feat_dim 256 behind two PositionalEncoders with pos_dim <= 128 and view_dir_dim <= 64 -- the
+        fused family and the wider inputs of coord_encode_level 11..20 / dir_encode_level 5..10."""
+        return self.feat_dim == 256 and self.pos_dim <= 128 and self.view_dir_dim <= 64 and self.knows_encoders
 
     @property
     def bf16_ok(self) -> bool:

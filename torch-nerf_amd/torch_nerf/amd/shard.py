@@ -156,8 +156,25 @@ def render_frame(camera, coarse_net, fine_net, n_coarse: int, n_fine: int, proje
         raise RuntimeError("render_frame: these networks are outside the fused family (feat_dim 256, pos_dim <= 64, "
                            "view_dir_dim <= 32 behind PositionalEncoders); pass the scene primitives (network + "
                            "encoders) instead of the bare networks so that the kernel chain can encode for them")
-    if (bf16 or f16x2) and not fused:
-        raise RuntimeError("render_frame(bf16 / f16x2): the bf16 and split-f16 kernels serve the fused family only")
+    if bf16 and not fused:
+        raise RuntimeError("render_frame(bf16=True): the bf16 kernel serves the fused family only")
+    if f16x2 and not fused:
+        # the kernel chain: scene.query_points picks the split-f16 kernel from the networks' own flag (feat_dim 256 behind
+        # PositionalEncoders with pos_dim <= 128, view_dir_dim <= 64); anything else would silently stay fp32 -- refuse
+        for sc in (coarse_scene, fine_scene):
+            spec = sc.raw_net()
+            if spec is None or not spec.f16x2_ok:
+                raise RuntimeError("render_frame(f16x2=True): the split-f16 kernel serves feat_dim 256 behind two "
+                                   "PositionalEncoders with pos_dim <= 128 and view_dir_dim <= 64")
+        saved_flags = [(net, net.f16x2_inference) for net in (coarse_net, fine_net)]
+        for net, _ in saved_flags:
+            net.f16x2_inference = True
+        try:
+            return render_frame(camera, coarse_scene, fine_scene, n_coarse, n_fine, project_to_ndc, seed, group,
+                                rays_per_launch, False, single_rank, stats, False)
+        finally:
+            for net, flag in saved_flags:
+                net.f16x2_inference = flag
     if fused:
         _, flat_c, packed_c = coarse_net._stream()
         _, flat_f, packed_f = fine_net._stream()
