@@ -843,6 +843,33 @@ def encoder_variants_leg(device, local_rank, steps, warmup, renderer=None):
             img = shard.render_frame(cam, scenes[0], scenes[1], N_COARSE, N_FINE, False, seed=1, single_rank=True)
             torch.cuda.synchronize()
             dt_frame = time.perf_counter() - t0
+            # round 6: the same step and frame with the networks' no-grad queries on the split-f16 kernel (PositionalEncoder
+            # scenes; the SH scene has no raw-point entry)
+            split = None
+            if scenes[0].raw_net() is not None and scenes[0].raw_net().f16x2_ok:
+                for sc in scenes:
+                    sc.radiance_field.f16x2_inference = True
+                torch.manual_seed(99)
+                _, x_rgb0 = render_step(renderer, scenes[0], scenes[1], pix[warmup], local_rank)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for s in range(warmup, warmup + steps):
+                    render_step(renderer, scenes[0], scenes[1], pix[s], local_rank)
+                torch.cuda.synchronize()
+                dtx = (time.perf_counter() - t0) / steps
+                for sc in scenes:
+                    sc.radiance_field.f16x2_inference = False
+                torch.manual_seed(99)
+                _, f_rgb0 = render_step(renderer, scenes[0], scenes[1], pix[warmup], local_rank)
+                t0 = time.perf_counter()
+                imgx = shard.render_frame(cam, scenes[0], scenes[1], N_COARSE, N_FINE, False, seed=1, single_rank=True, f16x2=True)
+                torch.cuda.synchronize()
+                dtx_frame = time.perf_counter() - t0
+                ex = (imgx - img).abs().max(dim=1).values
+                split = {"ms_per_step": dtx * 1e3, "rays_per_s": RAYS / dtx, "speedup_vs_fp32_step": dt / dtx,
+                         "step_max_abs_err_vs_fp32": float((x_rgb0 - f_rgb0).abs().max().item()),
+                         "frame_ms": dtx_frame * 1e3, "frame_pixels_beyond_1e-5": int((ex > 1e-5).sum().item()),
+                         "frame_median_abs_err_vs_fp32": float(ex.median().item())}
         macs = sum(o * i for o, i in synth.layer_shapes(ce.out_dim, de.out_dim, 256))
         flop = 2 * macs * RAYS * (2 * N_COARSE + N_FINE)
         # the training step on the same scenes (record forward, integrator + MLP backward, FusedAdam), as the `train` leg
@@ -873,7 +900,8 @@ def encoder_variants_leg(device, local_rank, steps, warmup, renderer=None):
                     "finite": bool(torch.isfinite(f_rgb).all()),
                     "train": {"ms_per_step": dt_train * 1e3, "rays_per_s": RAYS / dt_train,
                               "mlp_frac": 2 * (macs + bwd_macs) * RAYS * (2 * N_COARSE + N_FINE) / dt_train / 1e12 / FP32_MFMA_PEAK_TFLOPS},
-                    "frame": {"ms": dt_frame * 1e3, "rays_per_s": H * W / dt_frame, "finite": bool(torch.isfinite(img).all())}}
+                    "frame": {"ms": dt_frame * 1e3, "rays_per_s": H * W / dt_frame, "finite": bool(torch.isfinite(img).all())},
+                    "f16x2": split}
     out["what"] = ("4096 rays x (64+128), fp32, coarse + fine render_scene per step (the headline step's two calls) behind "
                    "non-default encoders: kernel chain sampling -> encode -> network -> integral; frame = 800x800 via "
                    "shard.render_frame(scenes)")

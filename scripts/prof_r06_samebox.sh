@@ -8,7 +8,7 @@ TAG=r06
 R=$GRAFT_REPO_ROOT
 OUT=/tmp/w/same_$TAG; mkdir -p $OUT $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 40 --warmup 5 --no-cpu-baseline --no-train --no-bf16 --no-frame --no-stages --no-traffic --no-configs --no-runner-loop"
+ARGS="--steps 40 --warmup 5 --no-cpu-baseline --no-train --no-bf16 --no-f16x2 --no-frame --no-stages --no-traffic --no-configs --no-runner-loop"
 python3 $R/bench.py $ARGS > $OUT/plain_a.json 2> $OUT/plain_a.err; echo "plain a rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py $ARGS > $OUT/profiled.json 2> $OUT/profiled.err; echo "trace rc=$?"
 python3 $R/bench.py $ARGS > $OUT/plain_b.json 2> $OUT/plain_b.err; echo "plain b rc=$?"
