@@ -319,6 +319,10 @@ struct GemmTable {
 struct GemmList {
     int n;
     int64_t work_total;
+    // round 6: the side jobs of the fc_8 / fc_9 items (density row and fc_out weight gradients summed beside the GEMM, from
+    // tiles that are in LDS anyway) for 256-feature layered networks: the planes they read and where fc_out.weight sits
+    const float *side_h9, *side_dsig, *side_gy;
+    int64_t off_wout;
 };
 
 __device__ __forceinline__ int64_t slice_stride(const GemmDesc &g) {
@@ -589,9 +593,13 @@ __device__ __forceinline__ void dw_body(const GemmDesc &g, int slice, int64_t t0
     }
 }
 
+// LIST: the layered family's list kernel (adds the window shape and the side-job addressing only it needs: the fused
+// family's table kernel compiles to the instruction stream it had before round 6)
+template <bool LIST>
 __device__ __forceinline__ void dw_main(const GemmDesc *items, int n_items, int64_t work_total,
-                                        const float *__restrict__ saved, const float *__restrict__ dy,
-                                        float *__restrict__ partial, int64_t M, char *lds) {
+                                        const float *__restrict__ saved_, const float *__restrict__ dy_,
+                                        float *__restrict__ partial, int64_t M, char *lds,
+                                        const GemmList *side = nullptr) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -620,6 +628,13 @@ __device__ __forceinline__ void dw_main(const GemmDesc *items, int n_items, int6
             __syncthreads();
         }
         first = false;
+        // side jobs address their planes as saved + pl_h9(MP), dy + dsig_plane(MP), dy + gy_plane(MP) (the fused family's
+        // record): a list names the planes themselves, the bases are backed out of them (never dereferenced elsewhere)
+        const float *saved = saved_, *dy = dy_;
+        if (LIST && side) {
+            saved = side->side_h9 - pl_h9(MP);
+            dy = (g.flags & FLAG_DENSITY) ? side->side_dsig - dsig_plane(MP) : side->side_gy - gy_plane(MP);
+        }
         if (g.flags & FLAG_DENSITY) {
             if (wave == 0) dw_body<2, 8, 0>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
             else if (wave == 1) dw_body<2, 8, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
@@ -644,6 +659,7 @@ __device__ __forceinline__ void dw_main(const GemmDesc *items, int n_items, int6
         else if (g.a_split == 4 && g.x_width == 64) dw_body<1, 2, -1, -1, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_split == 4) dw_body<1, 1, -1, -1, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 256 && g.x_width == 128) dw_body<2, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
+        else if (LIST && g.a_width == 256 && g.x_width == 96) dw_body<2, 3>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 256 && g.x_width == 32) dw_body<2, 1>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else if (g.a_width == 128 && g.x_width == 128) dw_body<1, 4>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
         else dw_body<1, 2>(g, slice, t0, t1, saved, dy, partial, MP, lds, tid, lane, wave);
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, con
                                                              unsigned long long *__restrict__ block_clocks) {
     const unsigned long long clk0 = block_clocks ? wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    dw_main(table.g, table.n, table.work_total, saved, dy, partial, M, lds);
+    dw_main<false>(table.g, table.n, table.work_total, saved, dy, partial, M, lds);
     if (block_clocks && threadIdx.x == 0) block_clocks[blockIdx.x] = wall_clock64() - clk0;  // 100 MHz ticks
 }
 
@@ -667,7 +683,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_list_kernel(const GemmList 
                                                                   float *__restrict__ partial, int64_t M) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const GemmDesc *items = reinterpret_cast<const GemmDesc *>(list + 1);
-    dw_main(items, list->n, list->work_total, nullptr, nullptr, partial, M, lds);
+    dw_main<true>(items, list->n, list->work_total, nullptr, nullptr, partial, M, lds, list->side_h9 ? list : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -679,7 +695,7 @@ __device__ __forceinline__ void reduce_item(const GemmDesc &g, const float *__re
 __global__ void mlp_bwd_reduce_list_kernel(const GemmList *__restrict__ list, const float *__restrict__ partial,
                                            float *__restrict__ g_params) {
     const GemmDesc *items = reinterpret_cast<const GemmDesc *>(list + 1);
-    if ((int)blockIdx.y < list->n) reduce_item(items[blockIdx.y], partial, 0, g_params);
+    if ((int)blockIdx.y < list->n) reduce_item(items[blockIdx.y], partial, list->off_wout, g_params);
 }
 
 __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__ partial,
@@ -843,10 +859,17 @@ struct DwItem {   // (mirrors the declaration in mlp_layered.hip)
     float *w_dst; int ld;
     int rows_valid, cols_valid;
     float *b_dst;
+    int row0;      // rows of the destination in front of the window's first row that w_dst / b_dst do NOT include (1 for an
+                   // fc_8 item with the density side job: its w_dst is the tensor's start, where the side job's row goes)
+    int side;      // 0 | 2 (FLAG_DENSITY) | 4 (FLAG_FCOUT)
+};
+struct DwSide {    // planes of the side jobs + where fc_out.weight sits in the flat gradient (mirrors mlp_layered.hip)
+    const float *h9, *dsig, *gy;
+    float *wout;
 };
 
 int64_t dw_items_scratch_bytes(int n_items) {
-    const int64_t list = (16 + (int64_t)n_items * (int64_t)sizeof(GemmDesc) + 255) & ~(int64_t)255;
+    const int64_t list = ((int64_t)sizeof(GemmList) + (int64_t)n_items * (int64_t)sizeof(GemmDesc) + 255) & ~(int64_t)255;
     return list + 4 * (int64_t)(512 + n_items) * (256 * 256 + SLICE_EXTRA);
 }
 
@@ -906,6 +929,13 @@ struct DwPlan {
     int64_t list_bytes = 0;       // header + descriptors, rounded to 256
     size_t host_bytes = 0;
 };
+// X-window width the kernel works on, in 32-feature blocks: 1 | 2 | 3 | 4 | 8.  Three blocks = the 96-wide position window
+// of coord_encode_level 11..15 next to a 256-row dY window (round 6: as a four-block window it cost 3750 units per tile
+// against 2850) -- other three-block windows keep the four-block shape.
+static int dw_item_kb(const DwItem &it) {
+    if (it.x_blocks == 3 && it.a_blocks > 4) return 3;
+    return it.x_blocks > 4 ? 8 : it.x_blocks > 2 ? 4 : it.x_blocks > 1 ? 2 : 1;
+}
 static void plan_dw_items(const std::vector<DwItem> &items, int64_t M, int cus, DwPlan &P) {
     const int n = (int)items.size();
     const int64_t MP = mlp::padded_rows(M), tiles = MP / 32;
@@ -914,14 +944,14 @@ static void plan_dw_items(const std::vector<DwItem> &items, int64_t M, int cus, 
         if (it.w_dst < P.base) P.base = it.w_dst;
         if (it.b_dst && it.b_dst < P.base) P.base = it.b_dst;
     }
-    P.host_bytes = 16 + (size_t)n * sizeof(GemmDesc);
+    P.host_bytes = sizeof(GemmList) + (size_t)n * sizeof(GemmDesc);
     P.G.resize(n);
     int64_t units = 0;
     for (int k = 0; k < n; ++k) {
         const DwItem &it = items[k];
         GemmDesc &g = P.G[k];
         const int NA = it.a_blocks > 4 ? 2 : 1;
-        const int KB = it.x_blocks > 4 ? 8 : it.x_blocks > 2 ? 4 : it.x_blocks > 1 ? 2 : 1;
+        const int KB = dw_item_kb(it);
         g.a_width = 128 * NA; g.x_width = 32 * KB;
         g.a_split = it.a_blocks <= 1 ? 4 : it.a_blocks <= 2 ? 2 : 1;
         // (a window wider than what is left of its plane runs on into the next tile's first blocks: finite values in
@@ -929,13 +959,14 @@ static void plan_dw_items(const std::vector<DwItem> &items, int64_t M, int cus, 
         g.a_src = reinterpret_cast<const char *>(it.a_plane + (int64_t)it.a_fb0 * 1024);
         g.x_src = reinterpret_cast<const char *>(it.x_plane + (int64_t)it.x_fb0 * 1024);
         g.a_stride = 128 * (int64_t)it.a_width; g.x_stride = 128 * (int64_t)it.x_width;
-        g.flags = it.b_dst ? FLAG_BIAS : 0;
-        g.in_features = it.ld; g.col0 = 0; g.row0 = 0;
+        g.flags = (it.b_dst ? FLAG_BIAS : 0) | it.side;
+        g.in_features = it.ld; g.col0 = 0; g.row0 = it.row0;
         g.valid_cols = it.cols_valid; g.valid_rows = it.rows_valid;
         g.w_off = it.w_dst - P.base; g.b_off = it.b_dst ? it.b_dst - P.base : 0;
         // relative tile times by shape (measured for the fused family's four shapes, mlp_backward.hip:make_plan)
         const int nk = NA * KB;
-        g.cost = nk == 16 ? 7350 : (NA == 1 && KB == 8) ? 3770 : (NA == 2 && KB == 2) ? 2010 : nk == 1 ? 935 : 450 * nk + 150;
+        g.cost = (it.side & FLAG_DENSITY) ? 7480 : (it.side & FLAG_FCOUT) ? 4145
+                 : nk == 16 ? 7350 : (NA == 1 && KB == 8) ? 3770 : (NA == 2 && KB == 2) ? 2010 : nk == 1 ? 935 : 450 * nk + 150;
         if (g.a_split > 1) {   // MFMA time of a wave's share, or the tile's bytes at the CU's share of HBM (~11 B / clock)
             const int mfma = 450 * KB / g.a_split + 150, hbm = 5 * (128 / g.a_split + 32 * KB);
             g.cost = mfma > hbm ? mfma : hbm;
@@ -977,13 +1008,14 @@ int64_t dw_items_needed_bytes(const std::vector<DwItem> &items, int64_t M, int c
 void dw_item_read_extent(const DwItem &it, int64_t M, int64_t *a_floats, int64_t *x_floats) {
     const int64_t tiles = mlp::padded_rows(M) / 32;
     const int NA = it.a_blocks > 4 ? 2 : 1;
-    const int KB = it.x_blocks > 4 ? 8 : it.x_blocks > 2 ? 4 : it.x_blocks > 1 ? 2 : 1;
+    const int KB = dw_item_kb(it);
     const int a_split = it.a_blocks <= 1 ? 4 : it.a_blocks <= 2 ? 2 : 1;
     *a_floats = (int64_t)it.a_fb0 * 1024 + (tiles - 1) * 32 * (int64_t)it.a_width + 32 * (int64_t)(128 * NA / a_split);
     *x_floats = (int64_t)it.x_fb0 * 1024 + (tiles - 1) * 32 * (int64_t)it.x_width + 32 * (int64_t)(32 * KB);
 }
 
-int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int64_t scratch_bytes, hipStream_t s) {
+int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int64_t scratch_bytes, hipStream_t s,
+                 const DwSide *side) {
     const int n = (int)items.size();
     if (n == 0 || M <= 0) return NERF_OK;
     static nerf::DeviceMask configured{0};
@@ -1001,9 +1033,11 @@ int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int
     char *host = ring.take(P.host_bytes, &slot);
     if (!host) return nerf::fail(NERF_ERR_LAUNCH, "nerf_mlp_layered_backward: pinned staging buffer for the dW item list");
     GemmList *hdr = reinterpret_cast<GemmList *>(host);
-    static_assert(sizeof(GemmList) == 16, "header size");
+    static_assert(sizeof(GemmList) % 8 == 0, "the descriptors behind the header stay 8-byte aligned");
     memcpy(host + sizeof(GemmList), P.G.data(), (size_t)n * sizeof(GemmDesc));
     hdr->n = n; hdr->work_total = P.units;
+    hdr->side_h9 = side ? side->h9 : nullptr; hdr->side_dsig = side ? side->dsig : nullptr; hdr->side_gy = side ? side->gy : nullptr;
+    hdr->off_wout = side ? side->wout - P.base : 0;
     if (hipMemcpyAsync(scratch, host, P.host_bytes, hipMemcpyHostToDevice, s) != hipSuccess)
         return nerf::check_launch("nerf_mlp_layered_backward: item list upload");
     ring.mark(slot, s);

@@ -36,8 +36,12 @@ struct DwItem {
     float *w_dst; int ld;                                 // dW[(a_fb0*32 + n) * ld + x_fb0*32 + k] destination (row n, col k)
     int rows_valid, cols_valid;                           // of the window
     float *b_dst;                                         // bias gradient for the window's rows, or null
+    int row0;                                             // destination rows in front of the window that w_dst / b_dst do not include
+    int side;                                             // 0 | 2 density row of fc_8 | 4 fc_out.weight: summed beside this item's GEMM
 };
-int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int64_t scratch_bytes, hipStream_t s);
+struct DwSide { const float *h9, *dsig, *gy; float *wout; };   // planes of the side jobs, fc_out.weight in the flat gradient
+int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int64_t scratch_bytes, hipStream_t s,
+                 const DwSide *side);
 int64_t dw_items_scratch_bytes(int n_items);
 int64_t dw_items_needed_bytes(const std::vector<DwItem> &items, int64_t M, int cus);                      // host only
 void dw_item_read_extent(const DwItem &it, int64_t M, int64_t *a_floats, int64_t *x_floats);            // host only
@@ -1431,13 +1435,15 @@ int launch_narrow_dx(bool ig, const WideArgs &a, hipStream_t s) {
 // coalesced 16-byte loads per lane; lane (i, h) keeps the partial sums of sample i of every tile in double, the 32
 // lanes of a half are added up once at the end.  Slices are summed in a fixed order by the second kernel: no atomics.
 constexpr int THIN_SLICES = 1024;   // (256 single-wavefront slices per block left the kernel latency-bound at 2.4 TB/s)
+// scalars_only (feat_dim 256: the rows are side jobs of the dW list kernel): two blocks per slice, the sums of dsig and of
+// gy only -- the four bias gradients -- without touching the h7 / h9 planes
 __global__ __launch_bounds__(64) void layered_thin_kernel(const Dims D, const float *__restrict__ rec,
                                                           const float *__restrict__ grad, int64_t MP, int slices,
-                                                          double *__restrict__ partial) {
+                                                          double *__restrict__ partial, int scalars_only) {
     const int cols = D.Fp + 3 * D.Hp + 4;
     const int blk = blockIdx.x, lane = threadIdx.x, i = lane & 31, h = lane >> 5;
-    const bool is_h7 = blk < D.Fp / 32;
-    const int fb = is_h7 ? blk : blk - D.Fp / 32;
+    const bool is_h7 = scalars_only ? blk == 0 : blk < D.Fp / 32;
+    const int fb = scalars_only ? 0 : is_h7 ? blk : blk - D.Fp / 32;
     const int width = is_h7 ? D.Fp : D.Hp;
     const float *plane = rec + (int64_t)(is_h7 ? D.r_h(7) : D.r_h9()) * MP;
     const float *gy = grad + (int64_t)D.g_gy() * MP, *ds = grad + (int64_t)D.g_dsig() * MP;
@@ -1459,7 +1465,7 @@ __global__ __launch_bounds__(64) void layered_thin_kernel(const Dims D, const fl
         for (int j = 0; j < TPT; ++j) {
             const int64_t tj = t + j < t1 ? t + j : t1 - 1;       // past the end: a re-read with zero weights
             const int64_t m = tj * 32 + i;
-            x[j] = load_block(plane + tj * 32 * width, fb, i, h);
+            if (!scalars_only) x[j] = load_block(plane + tj * 32 * width, fb, i, h);
             if (is_h7) g1[j] = t + j < t1 ? ds[m] : 0.0f;
             else {
                 g4[j] = *reinterpret_cast<const f32x4 *>(gy + 4 * m);
@@ -1471,10 +1477,12 @@ __global__ __launch_bounds__(64) void layered_thin_kernel(const Dims D, const fl
             if (is_h7) {
                 const double g = (double)g1[j];
                 if (h == 0) ssum[0] += g;
+                if (scalars_only) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] += g * (double)x[j][r];
             } else {
                 if (h == 0) { ssum[1] += (double)g4[j].x; ssum[2] += (double)g4[j].y; ssum[3] += (double)g4[j].z; }
+                if (scalars_only) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc[0][r] += (double)g4[j].x * (double)x[j][r];
@@ -1492,7 +1500,7 @@ __global__ __launch_bounds__(64) void layered_thin_kernel(const Dims D, const fl
     double *out = partial + (int64_t)blockIdx.y * cols;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        if (is_h7 && c > 0) break;
+        if ((is_h7 && c > 0) || scalars_only) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const double v = over_samples(acc[c][r]);
@@ -1509,9 +1517,9 @@ __global__ __launch_bounds__(64) void layered_thin_kernel(const Dims D, const fl
     }
 }
 __global__ __launch_bounds__(64) void layered_thin_reduce_kernel(const Dims D, const double *__restrict__ partial,
-                                                                 int slices, float *__restrict__ g_params) {
+                                                                 int slices, float *__restrict__ g_params, int first_col) {
     const int cols = D.Fp + 3 * D.Hp + 4;
-    const int col = blockIdx.x;
+    const int col = first_col + blockIdx.x;
     __shared__ double part[64];
     double acc = 0.0;
     for (int z = threadIdx.x; z < slices; z += 64) acc += partial[(int64_t)z * cols + col];   // fixed order per thread
@@ -1617,20 +1625,31 @@ NERF_API int64_t nerf_mlp_layered_workspace_bytes(const nerf_net_t *net, int64_t
 
 // The dW / db work list of one backward call: windows of <= 256 x 256 over (dY plane of the layer, its input plane(s)).
 // Pure pointer arithmetic on the three bases -- nerf_mlp_layered_plan_check runs it with stand-in bases, no GPU.
+// feat_dim 256: the density row of fc_8 and fc_out.weight are summed beside the fc_8 / fc_9 GEMMs (the fused family's side
+// jobs, mlp_backward.hip:dw_body) from tiles that are in LDS anyway, instead of a separate pass over the h7 and h9 planes
+// (1.2 GB per fine pass, 0.49 ms of a 27.8 ms step: profiles/r05_encoders_train_trace.txt)
+static bool dw_side_jobs(const Dims &D) { return D.F == 256; }
+static const float *rp_plane(const float *buffer, int off, int64_t MP) { return buffer + (int64_t)off * MP; }
+
 static void enumerate_dw_items(const Dims &D, int64_t MP, float *g_params, const float *rec, const float *grad,
                                std::vector<nerf::DwItem> &items) {
+    const bool side_jobs = dw_side_jobs(D);
     auto add = [&](int layer, const float *dy_plane, int n_w, int rows_total, int row0, const float *x_plane, int x_w,
-                   int cols_total, int col0, bool bias) {
+                   int cols_total, int col0, bool bias, int side = 0) {
         for (int fa = 0; fa * 32 < n_w; fa += 8)
             for (int fx = 0; fx * 32 < x_w; fx += 8) {
                 nerf::DwItem it;
                 it.a_plane = dy_plane; it.a_width = n_w; it.a_fb0 = fa; it.a_blocks = n_w / 32 - fa < 8 ? n_w / 32 - fa : 8;
                 it.x_plane = x_plane; it.x_width = x_w; it.x_fb0 = fx; it.x_blocks = x_w / 32 - fx < 8 ? x_w / 32 - fx : 8;
                 it.ld = D.in[layer];
-                it.w_dst = g_params + D.w[layer] + (int64_t)(row0 + fa * 32) * D.in[layer] + col0 + fx * 32;
+                // (an item with a side job keeps row0 OUT of its destinations: the reducer adds it, and the density row
+                // lands at the tensor's start)
+                it.side = side; it.row0 = side ? row0 : 0;
+                const int r0 = side ? 0 : row0;
+                it.w_dst = g_params + D.w[layer] + (int64_t)(r0 + fa * 32) * D.in[layer] + col0 + fx * 32;
                 it.rows_valid = rows_total - fa * 32 < 256 ? rows_total - fa * 32 : 256;
                 it.cols_valid = cols_total - fx * 32 < 256 ? cols_total - fx * 32 : 256;
-                it.b_dst = (bias && fx == 0) ? g_params + D.b[layer] + row0 + fa * 32 : nullptr;
+                it.b_dst = (bias && fx == 0) ? g_params + D.b[layer] + r0 + fa * 32 : nullptr;
                 if (it.rows_valid > 0 && it.cols_valid > 0) items.push_back(it);
             }
     };
@@ -1639,9 +1658,10 @@ static void enumerate_dw_items(const Dims &D, int64_t MP, float *g_params, const
     add(0, gp(D.g_dy(0)), D.Fp, D.F, 0, rp(D.r_pe()), D.Pp, D.E_p, 0, true);
     for (int l = 1; l <= 8; ++l) {
         if (l == 5) add(5, gp(D.g_dy(5)), D.Fp, D.F, 0, rp(D.r_pe()), D.Pp, D.E_p, 0, false);
-        add(l, gp(D.g_dy(l)), D.Fp, D.F, l == 8 ? 1 : 0, rp(D.r_h(l - 1)), D.Fp, D.F, l == 5 ? D.E_p : 0, true);
+        add(l, gp(D.g_dy(l)), D.Fp, D.F, l == 8 ? 1 : 0, rp(D.r_h(l - 1)), D.Fp, D.F, l == 5 ? D.E_p : 0, true,
+            (l == 8 && side_jobs) ? 2 : 0);
     }
-    add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_h(8)), D.Fp, D.F, 0, true);
+    add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_h(8)), D.Fp, D.F, 0, true, side_jobs ? 4 : 0);
     add(9, gp(D.g_dy9()), D.Hp, D.H, 0, rp(D.r_de()), D.Dp, D.E_d, D.F, false);
 }
 
@@ -1693,7 +1713,7 @@ NERF_API int nerf_mlp_layered_plan_check(const nerf_net_t *net, int64_t M, int c
         for (int l = 0; l < 10; ++l)
             if (w0 >= D.w[l] && w0 < D.w[l] + (int64_t)D.in[l] * D.out[l]) layer = l;
         PLAN_REQUIRE(layer >= 0 && it.ld == D.in[layer], "plan: item %d writes outside every weight tensor", (int)k);
-        const int64_t rel = w0 - D.w[layer], row = rel / it.ld, col = rel % it.ld;
+        const int64_t rel = w0 - D.w[layer], row = rel / it.ld + it.row0, col = rel % it.ld;
         PLAN_REQUIRE(it.rows_valid >= 1 && it.rows_valid <= 256 && it.cols_valid >= 1 && it.cols_valid <= 256 &&
                      row + it.rows_valid <= D.out[layer] && col + it.cols_valid <= D.in[layer],
                      "plan: item %d (layer %d) writes rows %lld+%d of %d, columns %lld+%d of %d", (int)k, layer, (long long)row,
@@ -1701,7 +1721,12 @@ NERF_API int nerf_mlp_layered_plan_check(const nerf_net_t *net, int64_t M, int c
         covered += (int64_t)it.rows_valid * it.cols_valid;
         if (it.b_dst) {
             const int64_t b0 = it.b_dst - PARAMS;
-            PLAN_REQUIRE(b0 >= D.b[layer] && b0 + it.rows_valid <= D.b[layer] + D.out[layer], "plan: item %d bias rows", (int)k);
+            PLAN_REQUIRE(b0 + it.row0 >= D.b[layer] && b0 + it.row0 + it.rows_valid <= D.b[layer] + D.out[layer], "plan: item %d bias rows", (int)k);
+        }
+        if (it.side) {      // side jobs: the 256 x 256 fc_8 item / the 128 x 256 fc_9 item of a 256-feature network, nothing else
+            PLAN_REQUIRE(D.F == 256 && ((it.side == 2 && layer == 8 && it.a_blocks == 8 && it.x_blocks == 8 && it.row0 == 1 && rel == 0) ||
+                                        (it.side == 4 && layer == 9 && it.a_blocks == 4 && it.x_blocks == 8 && it.row0 == 0 && rel == 0)),
+                         "plan: item %d carries side job %d it is not shaped for", (int)k, it.side);
         }
         PLAN_REQUIRE(it.a_blocks >= 1 && it.a_blocks <= 8 && it.x_blocks >= 1 && it.x_blocks <= 8 &&
                      it.a_blocks * 32 >= it.rows_valid && it.x_blocks * 32 >= it.cols_valid, "plan: item %d window blocks", (int)k);
@@ -1844,8 +1869,13 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
         int slices = (int)(MP / 32 / 8);           // >= 8 tiles per slice
         if (slices > THIN_SLICES) slices = THIN_SLICES;
         if (slices < 1) slices = 1;
-        hipLaunchKernelGGL(layered_thin_kernel, dim3((D.Fp + D.Hp) / 32, slices), dim3(64), 0, s, D, rec, grad, MP, slices, thin);
-        hipLaunchKernelGGL(layered_thin_reduce_kernel, dim3(cols), dim3(64), 0, s, D, thin, slices, g_params);
+        if (dw_side_jobs(D)) {   // the rows ride in the dW list kernel below; only the four bias sums are left
+            hipLaunchKernelGGL(layered_thin_kernel, dim3(2, slices), dim3(64), 0, s, D, rec, grad, MP, slices, thin, 1);
+            hipLaunchKernelGGL(layered_thin_reduce_kernel, dim3(4), dim3(64), 0, s, D, thin, slices, g_params, cols - 4);
+        } else {
+            hipLaunchKernelGGL(layered_thin_kernel, dim3((D.Fp + D.Hp) / 32, slices), dim3(64), 0, s, D, rec, grad, MP, slices, thin, 0);
+            hipLaunchKernelGGL(layered_thin_reduce_kernel, dim3(cols), dim3(64), 0, s, D, thin, slices, g_params, 0);
+        }
         if (int rc = nerf::check_launch("nerf_mlp_layered_backward: thin rows")) return rc;
     }
     // dW / db: windows of <= 256 x 256 over (dY plane of the layer, its input plane(s))
@@ -1853,5 +1883,7 @@ NERF_API int nerf_mlp_layered_backward(const nerf_net_t *net, const float *param
     enumerate_dw_items(D, MP, g_params, rec, grad, items);
     // (the bytes really left in the workspace nerf_mlp_layered_workspace_bytes sized, not a figure derived from the list)
     NERF_REQUIRE((int)items.size() <= dw_item_budget(D), "nerf_mlp_layered_backward: more dW windows than the workspace was sized for");
-    return nerf::run_dw_items(items, M, dw_scratch, nerf::dw_items_scratch_bytes(dw_item_budget(D)) + 65536, s);
+    nerf::DwSide side = {rp_plane(rec, D.r_h9(), MP), rp_plane(grad, D.g_dsig(), MP), rp_plane(grad, D.g_gy(), MP), g_params + D.w[10]};
+    return nerf::run_dw_items(items, M, dw_scratch, nerf::dw_items_scratch_bytes(dw_item_budget(D)) + 65536, s,
+                              dw_side_jobs(D) ? &side : nullptr);
 }
