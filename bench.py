@@ -720,6 +720,19 @@ def configs_leg(nets, flats, device):
     img = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, True, seed=2, single_rank=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the same LLFF frame on the split-f16 kernel (round 6)
+    shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, True, seed=2, single_rank=True, f16x2=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    imgl = shard.render_frame(cam, nets[0], nets[1], N_COARSE, N_FINE, True, seed=2, single_rank=True, f16x2=True)
+    torch.cuda.synchronize()
+    dtl = time.perf_counter() - t0
+    errl = (imgl - img).abs().max(dim=1).values
+    out["llff_f16x2"] = {"ms": dtl * 1e3, "rays_per_s": Hl * Wl / dtl, "rays": Hl * Wl, "dtype": "f16x2",
+                         "median_abs_err_vs_fp32_frame": float(errl.median().item()),
+                         "pixels_beyond_1e-5_of_fp32_frame": int((errl > 1e-5).sum().item()),
+                         "max_abs_err_vs_fp32_frame": float(errl.max().item()),
+                         "what": "the llff frame (configs[3]: 1008x756, NDC rays) with the MLP on the split-f16 kernel"}
     # ---- configs[2]: "Blender ship, 800x800, 64+128, bf16 MLP weights on MFMA": the whole frame on the bf16 path and
     # its PSNR against the fp32 frame of the same networks, pose and draws
     cam8 = cameras.PerspectiveCamera({"f_x": float(synth.blender_focal(W)), "f_y": float(synth.blender_focal(W)),

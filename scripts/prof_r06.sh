@@ -23,3 +23,4 @@ cd $R
 bash scripts/pmc_f16x2.sh $TAG > /dev/null 2>&1
 python3 bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err
 wc -l gpurun_out/${TAG}_*.txt; tail -c 600 gpurun_out/${TAG}_bench_n1.json; tail -5 gpurun_out/${TAG}_bench_n1.err
+bash scripts/prof_r06_encoders.sh > /dev/null 2>&1; head -8 gpurun_out/r06_encoders_train_trace.txt | cut -c1-150
