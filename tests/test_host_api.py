@@ -269,3 +269,17 @@ def test_nerf_parameters_share_one_blob_without_changing_the_module_surface():
     net = net.double().float()
     params = net._ordered_params()
     assert all(p.untyped_storage().data_ptr() == params[0].untyped_storage().data_ptr() for p in params)
+
+
+def test_f16x2_inference_default_comes_from_the_environment(monkeypatch):
+    """The runners construct their networks themselves (runner_utils.py:612, :638) and stay unmodified: the split-f16
+    inference kernel is switched on for them through the environment; the default is off (BASELINE names fp32)."""
+    monkeypatch.delenv("NERF_AMD_F16X2_INFERENCE", raising=False)
+    assert network.NeRF(63, 27).f16x2_inference is False
+    monkeypatch.setenv("NERF_AMD_F16X2_INFERENCE", "1")
+    net = network.NeRF(63, 27)
+    assert net.f16x2_inference is True and net.bf16_inference is False
+    net.f16x2_inference = False                       # still an ordinary per-instance attribute
+    assert network.NeRF(75, 27).f16x2_inference is True
+    monkeypatch.setenv("NERF_AMD_F16X2_INFERENCE", "0")
+    assert network.NeRF(63, 27).f16x2_inference is False

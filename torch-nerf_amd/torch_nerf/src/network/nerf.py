@@ -16,6 +16,7 @@ optimizer visibility); they are never called.  Two kernel families sit underneat
     ops.NerfLayeredFunction -- one persistent launch per forward / reverse chain (register-resident for feat_dim 256
     with pos_dim <= 128 and view_dir_dim <= 64, i.e. every coord_encode_level / dir_encode_level the yaml can name)
 """
+import os
 from typing import Tuple
 
 import torch
@@ -50,7 +51,10 @@ class NeRF(nn.Module):
         # Round 6: set to True to evaluate no-grad fused queries on the f16 matrix pipe with every operand split in two
         # f16 parts (three MFMAs per k-step, fp32 accumulate): the SAME 1e-5 bound as the fp32 kernels at ~3x their speed
         # (csrc/mlp_forward_f16x2.hip).  Takes precedence over bf16_inference.  Training always runs in fp32.
-        self.f16x2_inference = False
+        # The reference's runners build their networks themselves (runner_utils.py:612, :638) and are to stay unmodified:
+        # NERF_AMD_F16X2_INFERENCE=1 in the environment turns the flag on for every network they construct (validation
+        # renders, run_render.py); the attribute can still be set per instance afterwards.
+        self.f16x2_inference = os.environ.get("NERF_AMD_F16X2_INFERENCE", "0").lower() in ("1", "true", "on", "yes")
         self._packed_f16x2 = None
         self._flat_is_view = False
         self._rehome()
