@@ -101,11 +101,32 @@ def main():
                 print(json.dumps(entry), flush=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+    # round 6: the TRAINED networks on the split-f16 kernel (operands split in two f16 parts, csrc/mlp_forward_f16x2.hip) --
+    # trained weights are not nn.Linear's initial distribution: per-layer scales, activations and densities differ
+    split = None
+    if world == 1:
+        per_view = []
+        for i in range(held_images.shape[0]):
+            a = shard.render_frame(camera(held_poses[i]), coarse, fine, 64, 128, False, seed=1234, single_rank=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            b = shard.render_frame(camera(held_poses[i]), coarse, fine, 64, 128, False, seed=1234, single_rank=True, f16x2=True)
+            torch.cuda.synchronize()
+            dt_x = time.perf_counter() - t1
+            err = (a - b).abs().max(dim=1).values
+            per_view.append({"psnr_fp32": float(-10.0 * np.log10(torch.mean((a - held_images[i]) ** 2).item())),
+                             "psnr_f16x2": float(-10.0 * np.log10(torch.mean((b - held_images[i]) ** 2).item())),
+                             "median_abs_diff": float(err.median().item()), "max_abs_diff": float(err.max().item()),
+                             "pixels_beyond_1e-5": int((err > 1e-5).sum().item()), "pixels": int(err.numel()),
+                             "finite": bool(torch.isfinite(b).all()), "f16x2_frame_ms": dt_x * 1e3})
+        split = {"what": "held-out views of the trained networks: fp32 kernels vs the split-f16 kernel, same rays and draws",
+                 "views": per_view,
+                 "max_abs_weight": max(float(p.detach().abs().max()) for n in (coarse, fine) for p in n.parameters())}
     result = {"what": "procedural scene, coarse + fine NeRF, device-resident training step", "world": world,
               "size": size, "views": args.views, "rays_per_step": args.rays, "steps": args.steps,
               "train_seconds": train_s, "ms_per_step": 1e3 * train_s / args.steps,
               "rays_per_s": args.rays * args.steps / train_s, "psnr_heldout_start": log[0]["psnr_heldout"],
-              "psnr_heldout_end": log[-1]["psnr_heldout"], "log": log}
+              "psnr_heldout_end": log[-1]["psnr_heldout"], "f16x2_on_trained_networks": split, "log": log}
     if rank == 0:
         os.makedirs(args.out, exist_ok=True)
         with open(os.path.join(args.out, "train_procedural.json"), "w") as f:
