@@ -179,7 +179,30 @@ def train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank, steps, 
                 "backward": {"ms_per_step": round(bwd_ms / steps, 3), "TFLOPs": round(bwd_tf, 1),
                              "frac": round(bwd_tf / FP32_MFMA_PEAK_TFLOPS, 4)},
                 "other_ms_per_step": round(dt / steps * 1e3 - (fwd_ms + bwd_ms) / steps, 3)}
-    return {"rays_per_s": world * RAYS * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+    # round 6, opt-in variant: the same step with the RECORDING forward on the split-f16 kernel (NeRF.f16x2_training): the
+    # forward third at the f16 pipe's rate, the fp32 backward kernels unchanged behind the same record
+    split = None
+    if world == 1:
+        for net in nets:
+            net.f16x2_training = True
+        for s in range(2):
+            step(s)
+        fence()
+        ops.KERNEL_EVENTS = []
+        t0 = time.perf_counter()
+        for s in range(warmup, warmup + steps):
+            step(s % len(pix))
+        fence()
+        dtx = time.perf_counter() - t0
+        ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+        for net in nets:
+            net.f16x2_training = False
+        fx = [a.elapsed_time(b) for tag, M, a, b in ev if tag == "mlp_forward"]
+        split = {"ms_per_step": dtx / steps * 1e3, "rays_per_s": RAYS * steps / dtx, "speedup_vs_fp32_step": dt / dtx,
+                 "forward_record_ms_per_step": round(sum(fx) / steps, 3),
+                 "what": "NeRF.f16x2_training: record forward on the split-f16 kernel (same record, activations to 2^-22), "
+                         "fp32 dX / dW kernels, fused Adam"}
+    return {"rays_per_s": world * RAYS * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "f16x2_training": split,
             "what": "fwd+bwd+fused Adam+ExponentialLR, both networks, 4096 rays x (64 + 192) samples per GPU"
                     + (f", gradient all-reduce over {world} ranks" if world > 1 else ""),
             "mfma_frac_of_peak": flop / (dt / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "roofline": roofline}

@@ -148,6 +148,11 @@ int64_t nerf_mlp_packed_f16x2_bytes(const nerf_net_t *net);
 int nerf_mlp_pack_f16x2(const nerf_net_t *net, const float *params, void *packed_f16x2, nerf_stream_t stream);
 int nerf_mlp_forward_f16x2(const nerf_net_t *net, const void *packed_f16x2, const float *pos, const float *view_dir, int64_t M,
                            float *sigma, float *rgb, nerf_stream_t stream);
+/* The same forward as the TRAINING forward of the fused family: it also writes the activation record of
+ * nerf_mlp_forward(..., saved) -- `saved` = nerf_mlp_saved_bytes(net, M) bytes -- which nerf_mlp_backward (fp32 kernels)
+ * reads: the forward third of a training step at the split kernel's rate, activations recorded to 2^-22.  Raw points. */
+int nerf_mlp_forward_f16x2_record(const nerf_net_t *net, const void *packed_f16x2, const float *pos, const float *view_dir,
+                                  int64_t M, float *sigma, float *rgb, void *saved, nerf_stream_t stream);
 
 /* ---- a13 (MLP part): gradients of all 22 parameter tensors (autograd in the
  * reference, entered at runners/train.py:215).  g_params (param_count floats, same

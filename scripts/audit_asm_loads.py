@@ -102,6 +102,8 @@ def audit(path):
                         problems += 1
                         print(f"{path}:{no}: `{ln[:70]}` touches the result of the MFMA at line {d[2]} after {d[3]} wait "
                               f"state(s) (needs {MFMA_WAIT_STATES}: the compiler pads nothing inside asm)")
+        if op == "s_branch":     # an unconditional jump: what follows in the FILE does not follow in time
+            mfma_d = []
         m_n = re.fullmatch(r"s_nop (\d+)", ln)
         for d in mfma_d:
             d[3] += int(m_n.group(1)) + 1 if m_n else (16 if op.startswith("v_mfma") else 1)

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--eval-every", type=int, default=500)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--f16x2-training", action="store_true", help="record forward of every step on the split-f16 kernel "
+                    "(NeRF.f16x2_training, round 6); the backward stays the fp32 kernels")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "train_proc"))
     args = ap.parse_args()
 
@@ -59,6 +61,7 @@ def main():
 
     torch.manual_seed(args.seed)                        # same initial weights on every rank
     coarse, fine = NeRF(63, 27).to(dev), NeRF(63, 27).to(dev)
+    coarse.f16x2_training = fine.f16x2_training = bool(args.f16x2_training)
     opt = FusedAdam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, eps=1e-8)
     sched = torch.optim.lr_scheduler.ExponentialLR(opt, pow(0.00005 / 0.0005, 1 / 300000))
     gen = torch.Generator(device=dev).manual_seed(args.seed)   # identical on every rank: all agree on the batch
@@ -123,6 +126,7 @@ def main():
                  "views": per_view,
                  "max_abs_weight": max(float(p.detach().abs().max()) for n in (coarse, fine) for p in n.parameters())}
     result = {"what": "procedural scene, coarse + fine NeRF, device-resident training step", "world": world,
+              "f16x2_training": bool(args.f16x2_training),
               "size": size, "views": args.views, "rays_per_step": args.rays, "steps": args.steps,
               "train_seconds": train_s, "ms_per_step": 1e3 * train_s / args.steps,
               "rays_per_s": args.rays * args.steps / train_s, "psnr_heldout_start": log[0]["psnr_heldout"],

@@ -300,3 +300,52 @@ def test_sharded_frame_of_a_wide_encoder_scene_on_the_split_kernel():
     sh = scene.PrimitiveCube(network.NeRF(16, 16).cuda(), None)
     with pytest.raises(RuntimeError, match="split-f16"):
         shard.render_frame(cam, sh, sh, 64, 128, False, seed=5, single_rank=True, f16x2=True)
+
+
+def _mask_planes(saved, M):
+    MP = (M + 127) // 128 * 128
+    return saved.cpu().numpy().view(np.uint32)[MP * 2528:].reshape(9, MP, 2, 4)[:, :M]
+
+
+@pytest.mark.parametrize("M", [128, 1000, 20001])
+def test_record_forward_writes_the_fused_familys_record(oracle, M):
+    """mlp_forward_f16x2(save=True): the training forward on the split kernel.  Every plane of its record against the fp32
+    record kernel's (activations to the fp32 bound, ReLU bit planes equal except where the activation itself is within
+    rounding of zero), and the fp32 backward run ON this record against the oracle's gradients."""
+    from torch_nerf.amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(M)
+    xs = rng.uniform(-3.0, 3.0, (M, 3)).astype(np.float32)
+    vs = rng.uniform(-1.0, 1.0, (M, 3)).astype(np.float32)
+    gs, gc = rng.standard_normal(M).astype(np.float32), rng.standard_normal((M, 3)).astype(np.float32)
+    flat = synth.nerf_flat_params(seed=4, sigma_bias=1.0, sigma_gain=30.0)
+    p32, px = ops.mlp_pack(dev(flat)), ops.mlp_pack_f16x2(dev(flat))
+    s32, c32, rec32 = ops.mlp_forward(p32, dev(xs), dev(vs), False, save=True)
+    sx, cx, recx = ops.mlp_forward_f16x2(px, dev(xs), dev(vs), save=True)
+    assert recx.shape == rec32.shape
+    assert float((cx - c32).abs().max()) <= GOLDEN_ATOL
+    assert float(((sx - s32).abs() / s32.abs().clamp(min=1.0)).max()) <= GOLDEN_ATOL
+    MP = (M + 127) // 128 * 128
+    a, b = rec32.cpu().numpy(), recx.cpu().numpy()
+    planes = [("pe", 0, 64), ("de", MP * (64 + 256 * 9 + 128), 32), ("y8", MP * (64 + 256 * 8), 256), ("h9", MP * (64 + 256 * 9), 128)]
+    planes += [(f"h{l}", MP * (64 + 256 * l), 256) for l in range(8)]
+    rows = np.arange(M)
+    for name, off, width in planes:
+        idx = np.array([[lib.nerf_mlp_plane_offset(width, int(m), k) for k in range(width)] for m in rows[:: max(1, M // 97)]])
+        pa, pb = a[off + idx], b[off + idx]
+        scale = np.maximum(np.abs(pa), 1.0)
+        assert (np.abs(pa - pb) / scale).max() <= (0.0 if name in ("pe", "de") else GOLDEN_ATOL), name
+    ma, mb = _mask_planes(rec32, M), _mask_planes(recx, M)
+    differing = int(np.unpackbits((ma ^ mb).view(np.uint8)).sum())
+    assert differing <= max(2, int(2e-6 * M * 2176)), differing          # decisions on activations within rounding of zero
+    # the fp32 backward ON this record, every element of every gradient tensor against the oracle under the record's own
+    # ReLU decisions (the protocol of tests/test_gpu_backward.py: a decision on an activation within rounding of zero may
+    # fall either way, and both sides must then differentiate the same piecewise-linear function)
+    from helpers import assert_grads_match_given_masks, fused_masks
+    got = ops.mlp_backward(p32, dev(flat), dev(xs), dev(vs), False, sx, cx, recx, dev(gs), dev(gc)).cpu().numpy()
+    pe, de = oracle.posenc(xs, 10), oracle.posenc(vs, 4)
+    masks = fused_masks(recx, sx, M)
+    _, _, _, own = oracle.mlp_backward_ex(flat, pe, de, gs, gc, want_inputs=False, want_masks=True)
+    assert (masks != own).mean() < 1e-5
+    ref = oracle.mlp_backward_ex(flat, pe, de, gs, gc, want_inputs=False, force_masks=masks)[0]
+    assert_grads_match_given_masks(got, ref, synth.split_flat_params, f"M={M} ")

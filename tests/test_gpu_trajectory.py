@@ -64,7 +64,7 @@ def _make_net(flat, e_p=63, e_d=27):
     return net.cuda()
 
 
-def run_loop(g, optimizer_kind, monkeypatch):
+def run_loop(g, optimizer_kind, monkeypatch, f16x2_training=False):
     n, steps, init_lr, end_lr, num_iter, eps = g["config"]
     n, steps = int(n), int(steps)
     levels = tuple(int(v) for v in g["levels"])
@@ -72,6 +72,7 @@ def run_loop(g, optimizer_kind, monkeypatch):
     e_p, e_d = enc["coord_enc"].out_dim, enc["dir_enc"].out_dim
     flats = [synth.nerf_flat_params(seed=s, pos_dim=e_p, view_dir_dim=e_d, sigma_bias=1.0, sigma_gain=30.0) for s in (3, 4)]
     net_c, net_f = _make_net(flats[0], e_p, e_d), _make_net(flats[1], e_p, e_d)
+    net_c.f16x2_training = net_f.f16x2_training = f16x2_training
     default_scene, fine_scene = scene.PrimitiveCube(net_c, enc), scene.PrimitiveCube(net_f, enc)
     focal = float(synth.blender_focal(800))
 
@@ -144,6 +145,33 @@ def test_training_loop_follows_the_reference(golden, monkeypatch, optimizer_kind
               if max(abs(row["coarse_loss"]), abs(row["fine_loss"])) > LOSS_TYPICAL]
     assert len(beyond) <= LOSS_OUTLIERS, beyond
     first = drift["per_step"][0]           # before any optimizer step: the single-step accuracy, no chaos yet
+    assert max(abs(first["coarse_loss"]), abs(first["fine_loss"])) < 1e-7 and first["fine_rgb"] < 2e-6
+    for tag in ("coarse", "fine"):
+        d = drift[tag]
+        assert d["dp_norm_rel"] < DP_NORM_REL and d["dp_p99_rel_rms"] < DP_P99_REL_RMS and \
+            d["dp_rel_rms"] < DP_MAX_REL_RMS, (tag, d)
+
+
+def test_training_loop_with_the_split_f16_record_forward(golden, monkeypatch):
+    """NeRF.f16x2_training (round 6, opt-in): the RECORDING forward of every pass on the split-f16 kernel (activations
+    recorded to 2^-22 instead of 2^-24), the unchanged fp32 kernels behind it -- the same 20 iterations of the
+    reference's loop, held to the SAME bounds as the fp32 forward."""
+    g = golden("f14_train_loop")
+    calls = []
+    from torch_nerf.amd import ops
+    real = ops.mlp_forward_f16x2
+    monkeypatch.setattr(ops, "mlp_forward_f16x2", lambda *a, **k: (calls.append(k.get("save", False)), real(*a, **k))[1])
+    drift = run_loop(g, "fused", monkeypatch, f16x2_training=True)
+    assert len(calls) == 40 and all(calls)                     # coarse + fine record forward of all 20 steps took the kernel
+    print("F14 drift f16x2_training", json.dumps({k: v for k, v in drift.items() if k != "per_step"}))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(drift, open(os.path.join(out, "f14_train_loop_drift_f16x2_training.json"), "w"), indent=1)
+    assert drift["loss"] < LOSS_ATOL and drift["pixel"] < PIXEL_ATOL, (drift["loss"], drift["pixel"])
+    beyond = [i for i, row in enumerate(drift["per_step"])
+              if max(abs(row["coarse_loss"]), abs(row["fine_loss"])) > LOSS_TYPICAL]
+    assert len(beyond) <= LOSS_OUTLIERS, beyond
+    first = drift["per_step"][0]
     assert max(abs(first["coarse_loss"]), abs(first["fine_loss"])) < 1e-7 and first["fine_rgb"] < 2e-6
     for tag in ("coarse", "fine"):
         d = drift[tag]

@@ -56,6 +56,7 @@ struct SubPipe {
     int issue_q;           // position in the tile, [0, subs_per_tile), of the next sub-step to request
     unsigned consumed;     // sub-steps this wave has consumed
     int subs_per_tile;     // F2Layout::subs() of the network
+    int stores;            // (record mode) VMEM stores this wave has issued since its last rendezvous
 
     __device__ __forceinline__ void issue_piece(int p) const {
         lds_dma_16s(src_wave + issue_q * SUB_BYTES + p * 1024, lane_off,
@@ -69,6 +70,30 @@ struct SubPipe {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PIECES) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    }
+    // Record mode: the wave also has plane stores in flight.  gfx9 retires loads and stores through ONE in-order vmcnt, so
+    // "everything but the operations issued since the last rendezvous" is exact: those are this sub-step's PIECES DMA
+    // pieces + `stores` stores, all younger than the pieces of the sub-step being acquired (issued one rendezvous
+    // earlier).  s_waitcnt takes an immediate: a scalar jump table over the store count (capped low = waits for more).
+    __device__ __forceinline__ void rendezvous_recording() {
+        const int n = stores;
+        stores = 0;
+        if (n <= 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PIECES) : "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PIECES + 1) : "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PIECES + 2) : "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PIECES + 3) : "memory");
+        else if (n <= 5) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PIECES + 4) : "memory");
+        else if (n <= 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PIECES + 6) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PIECES + 9) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    template <bool RECORDING>
+    __device__ __forceinline__ unsigned acquire_as() {
+        if (RECORDING) rendezvous_recording(); else rendezvous();
+        const unsigned off = (consumed & (RING - 1)) * SUB_BYTES;
+        ++consumed;
+        return off;
     }
     __device__ __forceinline__ unsigned acquire() {
         rendezvous();
@@ -137,6 +162,59 @@ __device__ __forceinline__ void mma_kblock(f32x4 (&acc)[16], const f16x8 &bhi, c
     }
 }
 
+// Record mode (training forward): where this lane's four features of a 16-feature output block go in a plane of the fused
+// family's activation record (mlp_layout.h: TF layout; mlp_backward.hip reads it).  Lane (n, g) of wave w holds features
+// 16 fb + 4 g + e (e = 0..3) of sample m = 128 tile + 16 w + n: 32-feature block fb >> 1, quarter q = 2 (fb & 1) + (g >> 1),
+// lane half h = g & 1 -- one 16-byte store per block, 2 x 512 contiguous bytes per wavefront store.
+struct Recorder {
+    char *base;                 // the record
+    int64_t MP;                 // padded rows
+    int64_t tile32;             // m >> 5 (wave-uniform)
+    unsigned off_even, off_odd; // byte offset inside the (tile, 32-feature block) KiB run for even / odd fb
+    unsigned mask_unit;         // (2 (m & 31) + h) * 16: this lane's mask word inside the tile's 1-KiB mask run
+    int g;
+    __device__ __forceinline__ void open(float *saved, int64_t MP_, int64_t m, int g_) {
+        base = reinterpret_cast<char *>(saved);
+        MP = MP_;
+        tile32 = m >> 5;
+        g = g_;
+        const unsigned i = (unsigned)(m & 31), h = (unsigned)(g_ & 1), q0 = (unsigned)(g_ >> 1);
+        off_even = (q0 << 10) + 16u * ((2u * i + h) ^ (2u * q0));
+        off_odd = ((q0 + 2u) << 10) + 16u * ((2u * i + h) ^ (2u * (q0 + 2u)));
+        mask_unit = (2u * i + h) * 16u;
+    }
+    // plane at float offset `plane` (x MP already applied), `width` floats per sample; block fb of 16 features
+    __device__ __forceinline__ void store(int64_t plane, int width, int fb, const f32x4 &x, SubPipe &pipe) const {
+        char *p = base + 4 * (plane + tile32 * 32 * width) + (fb >> 1) * 4096 + ((fb & 1) ? off_odd : off_even);
+        *reinterpret_cast<f32x4 *>(p) = x;
+        ++pipe.stores;
+    }
+    // dword fb >> 2 of this lane's half of the (sample, h) mask word: bit 16 ((fb >> 1) & 1) + e + 4 q  <-  x[e] > 0
+    // (x is post-ReLU: > 0 <=> bit pattern != 0, mlp_device.h:save_mask)
+    __device__ __forceinline__ void mask_bits(int fb, const f32x4 &x, unsigned (&words)[4]) const {
+        unsigned w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned t;
+            asm("v_min_u32 %0, 1, %1" : "=v"(t) : "v"(x[e]));
+            w |= t << e;
+        }
+        words[fb >> 2] |= w << (16 * ((fb >> 1) & 1) + 8 * (fb & 1) + 4 * (g >> 1));
+    }
+    // mask plane l (0..7: h0..h7, 8: h9): lanes g and g ^ 2 hold the two halves of a word; lanes g < 2 store it
+    __device__ __forceinline__ void store_mask(int l, const unsigned (&words)[4], SubPipe &pipe) const {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[d] = words[d] | (unsigned)__shfl_xor((int)words[d], 32, WAVE);
+        if (g < 2) {
+            char *p = base + 4 * (pl_masks(MP) + (int64_t)l * MP * 8) + tile32 * 1024 + mask_unit;
+            *reinterpret_cast<u32x4 *>(p) = v;
+        }
+        ++pipe.stores;
+    }
+};
+
 // x (fp32, four features of one output block) -> elements 4 half .. 4 half + 3 of the hi / lo B fragments
 // `amax` follows the largest |x| this lane has split: beyond 65504 the hi part is inf, inf - inf = NaN in the next
 // accumulator and the ReLU behind it turns that into 0 -- a finite, wrong output.  The kernel poisons such a sample.
@@ -175,9 +253,12 @@ __device__ __forceinline__ void split4(const f32x4 &x, f16x8 &hi, f16x8 &lo, int
 // B fragments (hi, lo) of NKB 32-wide k-blocks of PositionalEncoder(3, levels, include_input).encode((x, y, z)) for lane
 // group g: element e of block kb is feature 32 kb + 16 (e>>2) + 4 g + (e&3) (positional_encoder.py:83-88), zero from
 // `width` = out_dim on
-template <int NKB, bool EXACT>
+// REC: also store the fp32 encodings into plane `plane` of the record (by reference + flag: a Recorder whose address is
+// taken conditionally ends up in scratch)
+template <int NKB, bool EXACT, bool REC>
 __device__ __forceinline__ void encode_split(float x, float y, float z, int g, int width, int include_input,
-                                             f16x8 (&hi)[NKB], f16x8 (&lo)[NKB], float &amax) {
+                                             f16x8 (&hi)[NKB], f16x8 (&lo)[NKB], float &amax,
+                                             const Recorder &rec, int64_t plane, SubPipe &pipe) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -185,18 +266,23 @@ __device__ __forceinline__ void encode_split(float x, float y, float z, int g, i
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = enc_feature<EXACT>(32 * kb + 16 * half + 4 * g + r, x, y, z, width, include_input);
+            if (REC) rec.store(plane, 32 * NKB, 2 * kb + half, v, pipe);       // PL_PE / PL_DE: the fp32 encodings
             split4(v, hi[kb], lo[kb], half, amax);
         }
 }
 
 // NPOS (2 | 3 | 4) position k-blocks, NDIR (1 | 2) direction k-blocks: <2, 1> is the fused family (the shipped 63 / 27 and
 // every coord_encode_level <= 10 / dir_encode_level <= 4); the others serve the wider encoders the yaml can name
-template <int NPOS, int NDIR>
+// SAVE (<2, 1> only): the TRAINING forward -- the same arithmetic, plus the fused family's activation record (post-ReLU
+// h0..h7, fc_8's output, h9, the fp32 encodings, ReLU bit planes) that mlp_backward.hip's fp32 kernels read
+template <int NPOS, int NDIR, bool SAVE = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const Net net, const char *__restrict__ packed,
                                                                            const float *__restrict__ pos,
                                                                            const float *__restrict__ dir, int64_t M,
                                                                            float *__restrict__ sigma_out,
-                                                                           float *__restrict__ rgb_out) {
+                                                                           float *__restrict__ rgb_out,
+                                                                           float *__restrict__ saved) {
+    static_assert(!SAVE || (NPOS == 2 && NDIR == 1), "the record is the fused family's");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -219,6 +305,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
     pipe.issue_q = 0;
     pipe.consumed = 0;
     pipe.subs_per_tile = F2Layout{NPOS, NDIR}.subs();
+    pipe.stores = 0;
+    const int64_t MP = padded_rows(M);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 2; ++q) {   // sub-steps 0 and 1 are in flight before the first rendezvous
@@ -256,6 +344,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
         f16x8 de_hi[NDIR], de_lo[NDIR];   // the encoded direction (fc_9): evaluated up front too, while nothing else is live
         float sigma_pre = 0.0f;
         float amax = 0.0f;             // largest magnitude split so far (f16 range check, see split4)
+        Recorder rec = {};
+        if (SAVE) rec.open(saved, MP, m, g);
+        unsigned mwords[4] = {0u, 0u, 0u, 0u};
         // (the lane group as a value hipcc cannot reason about: the feature-index arithmetic of the encodings would
         // otherwise be hoisted out of the tile loop and held in ~50 registers across the whole MFMA stream)
         int ge = g;
@@ -263,7 +354,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
 
         // one sub-step of a 256-row layer: one k-block against all 16 output blocks
         auto sub_step = [&](const f16x8 &bhi, const f16x8 &blo) {
-            const unsigned a = frag + pipe.acquire();
+            const unsigned a = frag + pipe.template acquire_as<SAVE>();
             mma_kblock<16, PIECES, 0, F2_IMAGE_BYTES>(acc, bhi, blo, a, pipe);
             pipe.issue_done();
         };
@@ -289,6 +380,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
                     const float v = acc[fb][r] * unscale;
                     x[r] = RELU ? relu1(v) : v;
                 }
+                if (SAVE) {      // layer l's activation (fc_8: its output, no ReLU) into the record; ReLU decisions as bits
+                    rec.store(l < 8 ? pl_h(MP, l) : pl_y8(MP), 256, fb, x, pipe);
+                    if (RELU) rec.mask_bits(fb, x, mwords);
+                    if (RELU && fb == 15) {
+                        rec.store_mask(l, mwords, pipe);
+                        mwords[0] = mwords[1] = mwords[2] = mwords[3] = 0u;
+                    }
+                }
                 if (DENSITY) {
                     const f32x4 w = *reinterpret_cast<const f32x4 *>(cb_ + CB_W8ROW0 + 16 * fb + 4 * g);
 #pragma unroll
@@ -309,7 +408,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
         // a 256 -> 256 layer whose inputs are the outputs of layer `prev` (ReLU in the seam): 8 sub-steps
         auto plain_layer = [&](int prev, auto density_tag, const float *bias) {
             seam_half(First(), Yes(), density_tag, Full(), prev, bias);
-            unsigned a = frag + pipe.acquire();
+            unsigned a = frag + pipe.template acquire_as<SAVE>();
             seam_half(Second(), Yes(), density_tag, Full(), prev, bias);
             mma_kblock<16, PIECES, 0, F2_IMAGE_BYTES>(acc, act_hi[0], act_lo[0], a, pipe);
             pipe.issue_done();
@@ -319,11 +418,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
 
         // ---- fc_in (nerf.py:102): sub-steps 0, 1
         if (exact) {
-            encode_split<NPOS, true>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo, amax);
-            encode_split<NDIR, true>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo, amax);
+            encode_split<NPOS, true, SAVE>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo, amax, rec, pl_pe(MP), pipe);
+            encode_split<NDIR, true, SAVE>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo, amax, rec, pl_de(MP), pipe);
         } else {
-            encode_split<NPOS, false>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo, amax);
-            encode_split<NDIR, false>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo, amax);
+            encode_split<NPOS, false, SAVE>(raw[0], raw[1], raw[2], ge, net.e_pos, net.inc_pos, pe_hi, pe_lo, amax, rec, pl_pe(MP), pipe);
+            encode_split<NDIR, false, SAVE>(raw[3], raw[4], raw[5], ge, net.e_dir, net.inc_dir, de_hi, de_lo, amax, rec, pl_de(MP), pipe);
         }
         load_bias_blocks(cb_ + CB_BIAS, 0, 16);
 #pragma unroll
@@ -333,7 +432,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
         // ---- fc_5 on cat([pos, x]) (:108): position FIRST
         {
             seam_half(First(), Yes(), No(), Full(), 4, cb_ + CB_BIAS + 5 * 256);
-            unsigned a = frag + pipe.acquire();
+            unsigned a = frag + pipe.template acquire_as<SAVE>();
             seam_half(Second(), Yes(), No(), Full(), 4, cb_ + CB_BIAS + 5 * 256);
             mma_kblock<16, PIECES, 0, F2_IMAGE_BYTES>(acc, pe_hi[0], pe_lo[0], a, pipe);
             pipe.issue_done();
@@ -350,19 +449,19 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
         // no ReLU (:113)
         {
             seam_half(First(), No(), No(), Half(), 8, cb_ + CB_BIAS9);
-            unsigned a = frag + pipe.acquire();
+            unsigned a = frag + pipe.template acquire_as<SAVE>();
             seam_half(Second(), No(), No(), Half(), 8, cb_ + CB_BIAS9);
             mma_kblock<8, PIECES, 0, F2_IMAGE_BYTES / 2>(acc, act_hi[0], act_lo[0], a, pipe);
             mma_kblock<8, 0, F2_IMAGE_BYTES, 3 * F2_IMAGE_BYTES / 2>(acc, act_hi[1], act_lo[1], a, pipe);
             pipe.issue_done();
 #pragma unroll
             for (int j = 1; j < 4; ++j) {
-                a = frag + pipe.acquire();
+                a = frag + pipe.template acquire_as<SAVE>();
                 mma_kblock<8, PIECES, 0, F2_IMAGE_BYTES / 2>(acc, act_hi[2 * j], act_lo[2 * j], a, pipe);
                 mma_kblock<8, 0, F2_IMAGE_BYTES, 3 * F2_IMAGE_BYTES / 2>(acc, act_hi[2 * j + 1], act_lo[2 * j + 1], a, pipe);
                 pipe.issue_done();
             }
-            a = frag + pipe.acquire();
+            a = frag + pipe.template acquire_as<SAVE>();
             mma_kblock<8, PIECES, 0, F2_IMAGE_BYTES / 2>(acc, de_hi[0], de_lo[0], a, pipe);     // (NDIR = 1: + a zero k-block, skipped)
             if (NDIR > 1) mma_kblock<8, 0, F2_IMAGE_BYTES, 3 * F2_IMAGE_BYTES / 2>(acc, de_hi[NDIR - 1], de_lo[NDIR - 1], a, pipe);
             pipe.issue_done();
@@ -377,6 +476,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
                 f32x4 x;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[r] = relu1(acc[fb][r] * unscale);
+                if (SAVE) {
+                    rec.store(pl_h9(MP), 128, fb, x, pipe);
+                    rec.mask_bits(fb, x, mwords);
+                    if (fb == 7) rec.store_mask(8, mwords, pipe);
+                }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const f32x4 w = *reinterpret_cast<const f32x4 *>(cb_ + CB_WOUT + c * HALF + 16 * fb + 4 * g);
@@ -421,10 +525,10 @@ NERF_API int nerf_mlp_forward_f16x2(const nerf_net_t *net_abi, const void *packe
     if (M == 0) return NERF_OK;
     NERF_REQUIRE(packed_f16x2 && pos && view_dir && sigma && rgb, "nerf_mlp_forward_f16x2: null pointer");
     const mlp::F2Layout L = mlp::f2_layout(net.e_pos, net.e_dir);
-    typedef void (*Kernel)(const Net, const char *, const float *, const float *, int64_t, float *, float *);
-    static const Kernel kernels[3][2] = {{mlp_forward_f16x2_kernel<2, 1>, mlp_forward_f16x2_kernel<2, 2>},
-                                         {mlp_forward_f16x2_kernel<3, 1>, mlp_forward_f16x2_kernel<3, 2>},
-                                         {mlp_forward_f16x2_kernel<4, 1>, mlp_forward_f16x2_kernel<4, 2>}};
+    typedef void (*Kernel)(const Net, const char *, const float *, const float *, int64_t, float *, float *, float *);
+    static const Kernel kernels[3][2] = {{mlp_forward_f16x2_kernel<2, 1, false>, mlp_forward_f16x2_kernel<2, 2, false>},
+                                         {mlp_forward_f16x2_kernel<3, 1, false>, mlp_forward_f16x2_kernel<3, 2, false>},
+                                         {mlp_forward_f16x2_kernel<4, 1, false>, mlp_forward_f16x2_kernel<4, 2, false>}};
     static nerf::DeviceMask configured[3][2] = {{{0}, {0}}, {{0}, {0}}, {{0}, {0}}};
     const Kernel kern = kernels[L.npos - 2][L.ndir - 1];
     if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), F2_LDS_BYTES, configured[L.npos - 2][L.ndir - 1],
@@ -433,6 +537,33 @@ NERF_API int nerf_mlp_forward_f16x2(const nerf_net_t *net_abi, const void *packe
     const int cus = nerf::device_cus();
     const int64_t ntiles = (M + TILE - 1) / TILE;
     hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(64 * WAVES), F2_LDS_BYTES,
-                       nerf::as_stream(stream), net, static_cast<const char *>(packed_f16x2), pos, view_dir, M, sigma, rgb);
+                       nerf::as_stream(stream), net, static_cast<const char *>(packed_f16x2), pos, view_dir, M, sigma, rgb,
+                       static_cast<float *>(nullptr));
     return nerf::check_launch("nerf_mlp_forward_f16x2");
+}
+
+// The TRAINING forward on the split kernel: same outputs, plus the activation record of nerf_mlp_forward(saved != NULL)
+// (nerf_mlp_saved_bytes), which nerf_mlp_backward reads.  Fused family behind PositionalEncoders, raw points.
+NERF_API int nerf_mlp_forward_f16x2_record(const nerf_net_t *net_abi, const void *packed_f16x2, const float *pos,
+                                           const float *view_dir, int64_t M, float *sigma, float *rgb, void *saved,
+                                           nerf_stream_t stream) {
+    mlp::Net net;
+    if (int rc = nerf::fused_net(net_abi, net, "nerf_mlp_forward_f16x2_record")) return rc;
+    if (!nerf::raw_inputs_ok(net))
+        return nerf::fail(NERF_ERR_UNSUPPORTED, "nerf_mlp_forward_f16x2_record: the kernel encodes raw points: nerf_net_t needs "
+                                                "the levels of both PositionalEncoders");
+    NERF_REQUIRE(M >= 0, "nerf_mlp_forward_f16x2_record: negative M");
+    if (M == 0) return NERF_OK;
+    NERF_REQUIRE(packed_f16x2 && pos && view_dir && sigma && rgb && saved, "nerf_mlp_forward_f16x2_record: null pointer");
+    auto kern = mlp_forward_f16x2_kernel<2, 1, true>;
+    static nerf::DeviceMask configured = {0};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), F2_LDS_BYTES, configured,
+                                          "nerf_mlp_forward_f16x2_record: LDS attribute"))
+        return rc;
+    const int cus = nerf::device_cus();
+    const int64_t ntiles = (M + TILE - 1) / TILE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(64 * WAVES), F2_LDS_BYTES,
+                       nerf::as_stream(stream), net, static_cast<const char *>(packed_f16x2), pos, view_dir, M, sigma, rgb,
+                       static_cast<float *>(saved));
+    return nerf::check_launch("nerf_mlp_forward_f16x2_record");
 }

@@ -392,9 +392,10 @@ def mlp_pack_f16x2(flat_params: torch.Tensor, net: Optional[Net] = None, out: Op
     return packed
 
 
-def mlp_forward_f16x2(packed_f16x2: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor, net: Optional[Net] = None):
-    """Inference-only split-f16 variant of the fused encode + NeRF forward (the fp32 bound on the f16 matrix pipe);
-    pos, view_dir raw (M,3)."""
+def mlp_forward_f16x2(packed_f16x2: torch.Tensor, pos: torch.Tensor, view_dir: torch.Tensor, net: Optional[Net] = None,
+                      save: bool = False):
+    """Split-f16 variant of the fused encode + NeRF forward (the fp32 bound on the f16 matrix pipe); pos, view_dir raw
+    (M,3).  save=True (fused family): also returns the activation record mlp_backward reads -- the training forward."""
     lib = _lib.load()
     pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
     _check_rows(pos, view_dir, False, net)
@@ -404,6 +405,19 @@ def mlp_forward_f16x2(packed_f16x2: torch.Tensor, pos: torch.Tensor, view_dir: t
     M = pos.shape[0]
     sigma = torch.empty((M,), dtype=torch.float32, device=pos.device)
     rgb = torch.empty((M, 3), dtype=torch.float32, device=pos.device)
+    if save:
+        nbytes = lib.nerf_mlp_saved_bytes(_ref(net), M)
+        if nbytes < 0:
+            raise RuntimeError(f"mlp_forward_f16x2(save=True): {lib.nerf_amd_last_error().decode()}")
+        saved = torch.empty((nbytes // 4,), dtype=torch.float32, device=pos.device)
+        with torch.cuda.device(pos.device):
+            end = _timed("mlp_forward", M)        # (the training legs' accounting: this IS the record forward)
+            _lib.check(lib.nerf_mlp_forward_f16x2_record(_ref(net), _ptr(packed_f16x2), _ptr(pos), _ptr(view_dir), M,
+                                                         _ptr(sigma), _ptr(rgb), _ptr(saved), _stream()),
+                       "nerf_mlp_forward_f16x2_record")
+            if end is not None:
+                end.record()
+        return sigma, rgb, saved
     with torch.cuda.device(pos.device):
         end = _timed("mlp_forward_f16x2", M)
         _lib.check(lib.nerf_mlp_forward_f16x2(_ref(net), _ptr(packed_f16x2), _ptr(pos), _ptr(view_dir), M, _ptr(sigma),
@@ -464,13 +478,22 @@ class NerfMLPFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, view_dir, encoded, record, packed, flat_params, net, *params):
+        # `packed`: the fp32 LDS-image stream, or (stream, split-f16 stream): with the second one given, a RECORDING forward
+        # on raw points runs on the split-f16 kernel (NeRF.f16x2_training) and writes the same record; the backward is
+        # the fp32 kernels' either way
+        packed_x2 = None
+        if isinstance(packed, tuple):
+            packed, packed_x2 = packed
         need_grad = bool(record)
         ctx.encoded = bool(encoded)
         ctx.net = net
         ctx.shapes = [p.shape for p in params]
         if need_grad:
             pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
-            sigma, rgb, saved = mlp_forward(packed, pos, view_dir, encoded, save=True, net=net)
+            if packed_x2 is not None and not encoded:
+                sigma, rgb, saved = mlp_forward_f16x2(packed_x2, pos, view_dir, net=net, save=True)
+            else:
+                sigma, rgb, saved = mlp_forward(packed, pos, view_dir, encoded, save=True, net=net)
             ctx.save_for_backward(pos, view_dir, packed, flat_params, sigma, rgb, saved)
         else:
             sigma, rgb = mlp_forward(packed, pos, view_dir, encoded, save=False, net=net)

@@ -56,6 +56,10 @@ class NeRF(nn.Module):
         # renders, run_render.py); the attribute can still be set per instance afterwards.
         self.f16x2_inference = os.environ.get("NERF_AMD_F16X2_INFERENCE", "0").lower() in ("1", "true", "on", "yes")
         self._packed_f16x2 = None
+        # Round 6, opt-in: run the RECORDING forward of a training step (raw points through the scene's fused query) on
+        # the split-f16 kernel as well -- the same activation record (activations to 2^-22 instead of 2^-24), read by the
+        # unchanged fp32 backward kernels: the forward third of the step at ~half its time.  Fused family only.
+        self.f16x2_training = os.environ.get("NERF_AMD_F16X2_TRAINING", "0").lower() in ("1", "true", "on", "yes")
         self._flat_is_view = False
         self._rehome()
 
@@ -236,6 +240,8 @@ class NeRF(nn.Module):
             self.warn_bf16_ignored(net)
         if not net.fused:     # layered family behind PositionalEncoders: raw points in, encodings straight into the planes
             return ops.NerfLayeredFunction.apply(points, view_dirs, record, flat, net, False, *params)
+        if record and self.f16x2_training and net.fused and net.knows_encoders:
+            packed = (packed, self._stream_f16x2())
         return ops.NerfMLPFunction.apply(points, view_dirs, False, record, packed, flat, net, *params)
 
     def warn_bf16_ignored(self, net=None):
