@@ -283,3 +283,10 @@ def test_f16x2_inference_default_comes_from_the_environment(monkeypatch):
     assert network.NeRF(75, 27).f16x2_inference is True
     monkeypatch.setenv("NERF_AMD_F16X2_INFERENCE", "0")
     assert network.NeRF(63, 27).f16x2_inference is False
+
+
+def test_f16x2_training_default_comes_from_the_environment(monkeypatch):
+    monkeypatch.delenv("NERF_AMD_F16X2_TRAINING", raising=False)
+    assert network.NeRF(63, 27).f16x2_training is False
+    monkeypatch.setenv("NERF_AMD_F16X2_TRAINING", "1")
+    assert network.NeRF(63, 27).f16x2_training is True
