@@ -128,7 +128,7 @@ def test_entry_points_refuse_what_they_cannot_serve_before_touching_the_gpu():
     # split-f16 variant (ABI v5): the fused family behind PositionalEncoders, mixed include_input allowed
     assert lib.nerf_mlp_forward_f16x2(sh, p, p, p, 4, p, p, None) == UNSUPPORTED and b"levels" in lib.nerf_amd_last_error()
     assert lib.nerf_mlp_forward_f16x2(f128, p, p, p, 4, p, p, None) == UNSUPPORTED
-    assert lib.nerf_mlp_packed_f16x2_bytes(f128) == -1 and lib.nerf_mlp_packed_f16x2_bytes(other) == 13312 + 73 * 32768
+    assert lib.nerf_mlp_packed_f16x2_bytes(f128) == -1 and lib.nerf_mlp_packed_f16x2_bytes(other) == 13312 + (73 + 68) * 32768   # forward + transposed stream
     wide = net(75, 33, 256, 12, 1, 5, 1)                                            # three position + two direction k-blocks
     assert lib.nerf_mlp_packed_f16x2_bytes(wide) == 13312 + (2 * 3 + 64 + 5) * 32768
     assert lib.nerf_mlp_packed_f16x2_bytes(net(129, 27, 256, -1, 0, -1, 0)) == -1 and b"split-f16" in lib.nerf_amd_last_error()

@@ -349,3 +349,34 @@ def test_record_forward_writes_the_fused_familys_record(oracle, M):
     assert (masks != own).mean() < 1e-5
     ref = oracle.mlp_backward_ex(flat, pe, de, gs, gc, want_inputs=False, force_masks=masks)[0]
     assert_grads_match_given_masks(got, ref, synth.split_flat_params, f"M={M} ")
+
+
+@pytest.mark.parametrize("M", [1, 127, 1000, 20001])
+def test_reverse_chain_on_the_split_kernel(oracle, M):
+    """nerf_mlp_backward_f16x2: stage 1 of the backward (dY(l-1) = W_l^T dY(l)) on the split-f16 kernel with a power-of-two
+    scale per sample, dW / reduction unchanged.  Gradients spanning eight decades between samples (upstream gradients
+    1e-6 .. 1e+2) must come out like the fp32 chain's: every element of every tensor against the oracle under the
+    record's ReLU decisions, and the gradient planes themselves against the fp32 chain's."""
+    from helpers import assert_grads_match_given_masks, fused_masks
+    rng = np.random.RandomState(M + 17)
+    xs = rng.uniform(-3.0, 3.0, (M, 3)).astype(np.float32)
+    vs = rng.uniform(-1.0, 1.0, (M, 3)).astype(np.float32)
+    mag = (10.0 ** rng.uniform(-6, 2, M)).astype(np.float32)               # per-sample magnitude: f16 alone would flush most
+    gs = (rng.standard_normal(M) * mag).astype(np.float32)
+    gc = (rng.standard_normal((M, 3)) * mag[:, None]).astype(np.float32)
+    if M > 3:
+        gs[1] = 0.0; gc[1] = 0.0                                           # a sample without any gradient
+    flat = synth.nerf_flat_params(seed=4, sigma_bias=1.0, sigma_gain=30.0)
+    p32, px = ops.mlp_pack(dev(flat)), ops.mlp_pack_f16x2(dev(flat))
+    sx, cx, rec = ops.mlp_forward(p32, dev(xs), dev(vs), False, save=True)
+    got = ops.mlp_backward(p32, dev(flat), dev(xs), dev(vs), False, sx, cx, rec, dev(gs), dev(gc), packed_f16x2=px).cpu().numpy()
+    ref32 = ops.mlp_backward(p32, dev(flat), dev(xs), dev(vs), False, sx, cx, rec, dev(gs), dev(gc)).cpu().numpy()
+    assert np.isfinite(got).all()
+    pe, de = oracle.posenc(xs, 10), oracle.posenc(vs, 4)
+    masks = fused_masks(rec, sx, M)
+    ref = oracle.mlp_backward_ex(flat, pe, de, gs, gc, want_inputs=False, force_masks=masks)[0]
+    assert_grads_match_given_masks(got, ref, synth.split_flat_params, f"split dX, M={M} ")
+    assert_grads_match_given_masks(ref32, ref, synth.split_flat_params, f"fp32 dX, M={M} ")
+    # twice: bit-identical (no atomics, fixed reduction order)
+    again = ops.mlp_backward(p32, dev(flat), dev(xs), dev(vs), False, sx, cx, rec, dev(gs), dev(gc), packed_f16x2=px).cpu().numpy()
+    assert np.array_equal(got, again)

@@ -1061,12 +1061,17 @@ NERF_API int64_t nerf_mlp_backward_workspace_bytes(const nerf_net_t *net, int64_
     return 4 * (align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE) + partial + (int64_t)BIAS_PARTIAL_FLOATS);
 }
 
-NERF_API int nerf_mlp_backward(const nerf_net_t *net_abi, const void *packed, const float *params, const float *pos,
-                               const float *view_dir, int64_t M, int encoded, const float *sigma,
-                               const float *rgb, const void *saved, const float *g_sigma, const float *g_rgb,
-                               float *g_params, float *g_pos, float *g_view_dir, void *workspace,
-                               nerf_stream_t stream) {
-    (void)params; (void)pos; (void)view_dir; (void)encoded;  // the saved record holds the encodings
+namespace nerf {   // mlp_forward_f16x2.hip: stage 1 on the split-f16 kernel
+int launch_dx_f16x2(const void *packed_f16x2, int64_t M, const float *sigma, const float *rgb, const float *g_sigma,
+                    const float *g_rgb, const float *saved, float *dy, float *bias_partial, int *partials, hipStream_t s);
+}
+
+// packed_f16x2 != NULL (and no input gradients asked for): stage 1, the reverse chain, runs on the split-f16 kernel; the
+// dW GEMMs and the reduction are the same fp32 kernels over the same planes
+static int backward_impl(const nerf_net_t *net_abi, const void *packed, const void *packed_f16x2, int64_t M, const float *sigma,
+                         const float *rgb, const void *saved, const float *g_sigma, const float *g_rgb,
+                         float *g_params, float *g_pos, float *g_view_dir, void *workspace,
+                         nerf_stream_t stream) {
     mlp::Net net;
     if (int rc = nerf::fused_net(net_abi, net, "nerf_mlp_backward")) return rc;
     NERF_REQUIRE(M >= 0, "nerf_mlp_backward: negative M");
@@ -1098,9 +1103,15 @@ NERF_API int nerf_mlp_backward(const nerf_net_t *net_abi, const void *packed, co
 
     const int64_t ntiles = MP / mlp::TILE_SAMPLES;
     const unsigned dx_grid = (unsigned)(ntiles < cus ? ntiles : (cus < 1024 ? cus : 1024));
-    hipLaunchKernelGGL(dx_kernel, dim3(dx_grid), dim3(256), mlp::LDS_BYTES, s,
-                       static_cast<const char *>(packed), M, sigma, rgb, g_sigma, g_rgb, sv, dy, bias_partial);
-    int rc = nerf::check_launch("nerf_mlp_backward: dx chain");
+    int bias_partials = (int)dx_grid * 4;
+    int rc;
+    if (packed_f16x2 && !input_grads) {
+        rc = nerf::launch_dx_f16x2(packed_f16x2, M, sigma, rgb, g_sigma, g_rgb, sv, dy, bias_partial, &bias_partials, s);
+    } else {
+        hipLaunchKernelGGL(dx_kernel, dim3(dx_grid), dim3(256), mlp::LDS_BYTES, s,
+                           static_cast<const char *>(packed), M, sigma, rgb, g_sigma, g_rgb, sv, dy, bias_partial);
+        rc = nerf::check_launch("nerf_mlp_backward: dx chain");
+    }
     if (rc != NERF_OK) return rc;
     if (input_grads) {
         const int64_t total = M * (int64_t)(net.e_pos + net.e_dir);
@@ -1132,7 +1143,27 @@ NERF_API int nerf_mlp_backward(const nerf_net_t *net_abi, const void *packed, co
         }
     }
     hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(256, plan.table.n + 1), dim3(256), 0, s, plan.table,
-                       static_cast<const float *>(partial), static_cast<const float *>(bias_partial), (int)dx_grid * 4,
+                       static_cast<const float *>(partial), static_cast<const float *>(bias_partial), bias_partials,
                        g_params);
     return nerf::check_launch("nerf_mlp_backward: reduce");
+}
+
+NERF_API int nerf_mlp_backward(const nerf_net_t *net_abi, const void *packed, const float *params, const float *pos,
+                               const float *view_dir, int64_t M, int encoded, const float *sigma,
+                               const float *rgb, const void *saved, const float *g_sigma, const float *g_rgb,
+                               float *g_params, float *g_pos, float *g_view_dir, void *workspace,
+                               nerf_stream_t stream) {
+    (void)params; (void)pos; (void)view_dir; (void)encoded;  // the saved record holds the encodings
+    return backward_impl(net_abi, packed, nullptr, M, sigma, rgb, saved, g_sigma, g_rgb, g_params, g_pos, g_view_dir,
+                         workspace, stream);
+}
+
+// The same with the reverse chain (dX) on the split-f16 kernel: packed_f16x2 = the nerf_mlp_pack_f16x2 stream of the same
+// parameters (its transposed half).  Parameter gradients only (input gradients: nerf_mlp_backward).
+NERF_API int nerf_mlp_backward_f16x2(const nerf_net_t *net_abi, const void *packed, const void *packed_f16x2, int64_t M,
+                                     const float *sigma, const float *rgb, const void *saved, const float *g_sigma,
+                                     const float *g_rgb, float *g_params, void *workspace, nerf_stream_t stream) {
+    NERF_REQUIRE(packed_f16x2, "nerf_mlp_backward_f16x2: null packed_f16x2");
+    return backward_impl(net_abi, packed, packed_f16x2, M, sigma, rgb, saved, g_sigma, g_rgb, g_params, nullptr, nullptr,
+                         workspace, stream);
 }

@@ -512,6 +512,220 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The reverse chain (dX) on the split kernel: dY^T(l-1) = W_l^T dY^T(l), the fused family's mlp_bwd_dx_kernel (mlp_backward.hip)
+// with split operands.  Same inputs (the forward's record: ReLU bit planes; sigma, rgb, their gradients), same outputs (the
+// gradient planes dY0..dY8, dY9, dsig, gy in the workspace the fp32 dW kernel reads; per-wavefront sums of the four scalar
+// bias gradients).
+// Gradients are not O(1) like activations: a sample's dY can sit at 1e-7, where f16 has no bits left.  Samples are the
+// COLUMNS of these MFMAs, so every sample carries its own power-of-two scale: before a layer's dY is split it is multiplied
+// by 2^t with t chosen from the sample's largest |dY| (-> [2^9, 2^10)), and the seam behind the contraction divides it out
+// again (exact) before the plane store.  Within a column, elements below 2^-22 of its largest lose relative precision --
+// they are below the fp32 rounding of the sums they enter.
+__device__ __forceinline__ float column_scale(float amax_lane) {
+    float a = fmaxf(amax_lane, __shfl_xor(amax_lane, 16, WAVE));
+    a = fmaxf(a, __shfl_xor(a, 32, WAVE));
+    int e;
+    (void)frexpf(a, &e);                       // a = f 2^e, f in [0.5, 1)
+    int t = 10 - e;
+    t = t > 100 ? 100 : (t < -100 ? -100 : t);
+    return (a > 0.0f && a < INFINITY) ? ldexpf(1.0f, t) : 1.0f;
+}
+
+__global__ __launch_bounds__(64 * WAVES, 1) void mlp_bwd_dx_f16x2_kernel(const char *__restrict__ packed, int64_t M,
+                                                                          const float *__restrict__ sigma,
+                                                                          const float *__restrict__ rgb,
+                                                                          const float *__restrict__ g_sigma,
+                                                                          const float *__restrict__ g_rgb,
+                                                                          const float *__restrict__ saved,
+                                                                          float *__restrict__ dy,
+                                                                          float *__restrict__ bias_partial) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    float *cb_ = reinterpret_cast<float *>(lds);
+    const unsigned ring = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)CONST_BYTES;
+    for (int e = tid; e < CONST_FLOATS / 4; e += 64 * WAVES)
+        reinterpret_cast<f32x4 *>(cb_)[e] = reinterpret_cast<const f32x4 *>(packed)[e];
+    const unsigned frag = ring + (unsigned)f2_frag_offset(n, g);
+
+    SubPipe pipe;
+    pipe.src_wave = packed + CONST_BYTES + (int64_t)F2_SUBS * SUB_BYTES + wave * (PIECES * 1024);   // the transposed stream
+    pipe.lane_off = (unsigned)lane * 16u;
+    pipe.lds_wave = ring + (unsigned)wave * (PIECES * 1024u);
+    pipe.issued = 0;
+    pipe.issue_q = 0;
+    pipe.consumed = 0;
+    pipe.subs_per_tile = F2_BWD_SUBS;
+    pipe.stores = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) pipe.issue_piece(p);
+        pipe.issue_done();
+    }
+    const int64_t MP = padded_rows(M);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *masks = reinterpret_cast<const u32x4 *>(saved + pl_masks(MP));
+    const int64_t ntiles = MP / TILE;
+    float bsum4[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned gshift = 4u * (unsigned)(g >> 1);
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t m = tile * TILE + wave * WSAMPLES + n;
+        const bool valid = m < M;
+        const int64_t mc = valid ? m : M - 1;
+        float gy[3], yv[3], gv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { yv[c] = rgb[3 * mc + c]; gv[c] = g_rgb[3 * mc + c]; }
+        const float sg = sigma[mc], gsg = g_sigma[mc];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {       // fc_out + sigmoid (nerf.py:119): d y10 = g_rgb * rgb * (1 - rgb)
+            const float t = gv[c] * yv[c] * (1.0f - yv[c]);
+            gy[c] = valid ? t : 0.0f;
+        }
+        const float dsig = (valid && sg > 0.0f) ? gsg : 0.0f;      // sigma = relu(y8[0]) (:115)
+        if (g == 0) {
+            const f32x4 g4 = {gy[0], gy[1], gy[2], 0.0f};
+            *reinterpret_cast<f32x4 *>(dy + gy_plane(MP) + 4 * m) = g4;
+            dy[dsig_plane(MP) + m] = dsig;
+            bsum4[0] += gy[0]; bsum4[1] += gy[1]; bsum4[2] += gy[2]; bsum4[3] += dsig;
+        }
+        pipe.stores += 2;
+
+        Recorder rec = {};
+        rec.open(dy, MP, m, g);
+        f32x4 acc[16];
+        f16x8 act_hi[8], act_lo[8];
+        float dummy = 0.0f;
+        // this lane's ReLU bits of plane `l`, shifted so that bit 16 ((fb >> 1) & 1) + 8 (fb & 1) + e of dword fb >> 2 is feature
+        // 16 fb + 4 g + e (Recorder::mask_bits writes them at + 4 (g >> 1))
+        auto load_mask = [&](int l) {
+            u32x4 mk = masks[(int64_t)l * MP * 2 + 2 * m + (g & 1)];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) mk[d] >>= gshift;
+            return mk;
+        };
+        auto masked4 = [&](const u32x4 &mk, int fb, f32x4 v) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int keep;
+                const int bit = 16 * ((fb >> 1) & 1) + 8 * (fb & 1) + e;
+                switch (bit) {     // (v_bfe_i32 takes the offset as an immediate)
+#define NERF_KEEP(B) case B: asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(mk[fb >> 2]), "n"(B)); break;
+                    NERF_KEEP(0) NERF_KEEP(1) NERF_KEEP(2) NERF_KEEP(3) NERF_KEEP(8) NERF_KEEP(9) NERF_KEEP(10) NERF_KEEP(11)
+                    NERF_KEEP(16) NERF_KEEP(17) NERF_KEEP(18) NERF_KEEP(19) NERF_KEEP(24) NERF_KEEP(25) NERF_KEEP(26) NERF_KEEP(27)
+#undef NERF_KEEP
+                    default: keep = 0;
+                }
+                // (through a scalar: __builtin_bit_cast applied to the element expression v[e] itself reads element 0 of the
+                // vector whatever e is -- clang 19 / ROCm 7.2 -- and every lane's e = 1..3 came out as keep_e & keep_0 & v[0])
+                const float t = v[e];
+                v[e] = __builtin_bit_cast(float, __builtin_bit_cast(int, t) & keep);
+            }
+            return v;
+        };
+        // NB blocks of dY held in acc[] (true values) -> packed hi / lo of dY * 2^t; returns 2^-t
+        auto scale_and_split = [&](auto nb_tag) {
+            constexpr int NB = decltype(nb_tag)::value;
+            float amax = 0.0f;
+#pragma unroll
+            for (int fb = 0; fb < NB; ++fb) {
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(acc[fb][0]), "v"(acc[fb][1]));
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(acc[fb][2]), "v"(acc[fb][3]));
+            }
+            const float cs = column_scale(amax);
+#pragma unroll
+            for (int fb = 0; fb < NB; ++fb) {
+                const f32x4 x = acc[fb] * cs;
+                split4(x, act_hi[fb >> 1], act_lo[fb >> 1], fb & 1, dummy);
+            }
+            return 1.0f / cs;
+        };
+        typedef std::integral_constant<int, 8> Eight;
+        typedef std::integral_constant<int, 16> Sixteen;
+
+        // ---- dY9 = (W_out^T d y10) . [h9 > 0]   (vector ALU, 3 x 128 MACs per sample)
+        u32x4 mk = load_mask(8);
+#pragma unroll
+        for (int fb = 0; fb < 8; ++fb) {
+            const int k0 = 16 * fb + 4 * g;
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(cb_ + CB_WOUT + k0);
+            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(cb_ + CB_WOUT + HALF + k0);
+            const f32x4 w2 = *reinterpret_cast<const f32x4 *>(cb_ + CB_WOUT + 2 * HALF + k0);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(w2[e], gy[2], fmaf(w1[e], gy[1], w0[e] * gy[0]));
+            acc[fb] = masked4(mk, fb, v);
+            rec.store(dy9_plane(MP), 128, fb, acc[fb], pipe);
+        }
+        float inv_cs = scale_and_split(Eight());
+        u32x4 mk_next = load_mask(7);
+        // ---- d y8[1:257] = W9[:, 0:256]^T dY9: four sub-steps, accumulators from zero
+#pragma unroll
+        for (int fb = 0; fb < 16; ++fb) acc[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const unsigned a = frag + pipe.template acquire_as<true>();
+            mma_kblock<16, PIECES, 0, F2_IMAGE_BYTES>(acc, act_hi[kb], act_lo[kb], a, pipe);
+            pipe.issue_done();
+        }
+        // ---- l = 8 .. 1: dY(l) = [previous contraction] . [h_l > 0] (fc_8 has no ReLU), stored; dY(l-1) pre-mask = W_l^T dY(l)
+        for (int l = 8; l >= 1; --l) {
+            const float un = cb_[F2_CB_UNSCALE + (l == 8 ? 9 : l + 1)] * inv_cs;
+            mk = mk_next;
+#pragma unroll
+            for (int fb = 0; fb < 16; ++fb) {
+                f32x4 x = acc[fb] * un;
+                if (l < 8) x = masked4(mk, fb, x);
+                acc[fb] = x;
+                rec.store(dy_plane(MP, l), 256, fb, x, pipe);
+            }
+            if (l > 1) mk_next = load_mask(l == 8 ? 7 : l - 1);      // (l = 8 uses none: h7's bits serve the seam of l = 7)
+            else mk_next = load_mask(0);
+            inv_cs = scale_and_split(Sixteen());
+            if (l == 8) {      // the density row of fc_8 contributes w8[0, k] * d y8[0]: into the (scaled) accumulators
+                const float init = dsig * cb_[F2_CB_SCALE + 8] / inv_cs;
+#pragma unroll
+                for (int fb = 0; fb < 16; ++fb) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(cb_ + CB_W8ROW0 + 16 * fb + 4 * g);
+                    acc[fb] = wv * init;
+                }
+            } else {
+#pragma unroll
+                for (int fb = 0; fb < 16; ++fb) acc[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const unsigned a = frag + pipe.template acquire_as<true>();
+                mma_kblock<16, PIECES, 0, F2_IMAGE_BYTES>(acc, act_hi[kb], act_lo[kb], a, pipe);
+                pipe.issue_done();
+            }
+        }
+        // ---- dY0: mask with h0 and store (the encodings carry no gradient)
+        {
+            const float un = cb_[F2_CB_UNSCALE + 1] * inv_cs;
+#pragma unroll
+            for (int fb = 0; fb < 16; ++fb) {
+                const f32x4 x = masked4(mk_next, fb, acc[fb] * un);
+                rec.store(dy_plane(MP, 0), 256, fb, x, pipe);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = bsum4[c];       // lanes of the other lane groups hold zeros
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+        if (lane == 0) bias_partial[((int64_t)blockIdx.x * WAVES + wave) * 4 + c] = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 NERF_API int nerf_mlp_forward_f16x2(const nerf_net_t *net_abi, const void *packed_f16x2, const float *pos,
@@ -567,3 +781,22 @@ NERF_API int nerf_mlp_forward_f16x2_record(const nerf_net_t *net_abi, const void
                        static_cast<float *>(saved));
     return nerf::check_launch("nerf_mlp_forward_f16x2_record");
 }
+
+// mlp_backward.hip calls this for stage 1 when it is handed a split-f16 stream (nerf_mlp_backward_f16x2): the reverse chain
+// on the f16 matrix pipe; `partials` = number of per-wavefront bias partials written (the reducer's loop bound)
+namespace nerf {
+int launch_dx_f16x2(const void *packed_f16x2, int64_t M, const float *sigma, const float *rgb, const float *g_sigma,
+                    const float *g_rgb, const float *saved, float *dy, float *bias_partial, int *partials, hipStream_t s) {
+    static nerf::DeviceMask configured = {0};
+    if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_dx_f16x2_kernel), F2_LDS_BYTES, configured,
+                                          "nerf_mlp_backward_f16x2: LDS attribute (dX)"))
+        return rc;
+    const int cus = nerf::device_cus();
+    const int64_t ntiles = mlp::padded_rows(M) / TILE;
+    const unsigned grid = (unsigned)(ntiles < cus ? ntiles : (cus < 512 ? cus : 512));
+    hipLaunchKernelGGL(mlp_bwd_dx_f16x2_kernel, dim3(grid), dim3(64 * WAVES), F2_LDS_BYTES, s,
+                       static_cast<const char *>(packed_f16x2), M, sigma, rgb, g_sigma, g_rgb, saved, dy, bias_partial);
+    *partials = (int)grid * WAVES;
+    return nerf::check_launch("nerf_mlp_backward_f16x2: dx chain");
+}
+}  // namespace nerf

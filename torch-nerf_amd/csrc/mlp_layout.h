@@ -227,13 +227,18 @@ struct F2Layout {
     __host__ __device__ constexpr int sub_fc8() const { return 2 * npos + 56; }
     __host__ __device__ constexpr int sub_fc9() const { return 2 * npos + 64; }
     __host__ __device__ constexpr int subs() const { return 2 * npos + 64 + (8 + ndir + 1) / 2; }
-    __host__ __device__ constexpr int64_t packed_bytes() const { return (int64_t)CONST_BYTES + (int64_t)subs() * F2_SUB_BYTES; }
+    // the fused family's stream (npos 2, ndir 1) is followed by the TRANSPOSED stream of the reverse chain
+    // (mlp_bwd_dx_f16x2_kernel): fc_9[:, 0:256]^T in 4 sub-steps, then fc_8[1:257]^T, fc_7^T .. fc_1^T (fc_5: its 256
+    // feature columns) in 8 each -- image row = INPUT feature of the layer, k = its output features, same fragment format
+    __host__ __device__ constexpr int bwd_subs() const { return (npos == 2 && ndir == 1) ? 4 + 8 * 8 : 0; }
+    __host__ __device__ constexpr int64_t packed_bytes() const { return (int64_t)CONST_BYTES + (int64_t)(subs() + bwd_subs()) * F2_SUB_BYTES; }
 };
 __host__ __device__ constexpr F2Layout f2_layout(int e_pos, int e_dir) {
     return F2Layout{e_pos <= 64 ? 2 : (e_pos + 31) / 32, (e_dir + 31) / 32};
 }
 constexpr int F2_SUBS = f2_layout(63, 27).subs();           // 73: the shipped network
 static_assert(F2_SUBS == 73, "split-f16 stream of NeRF(63, 27, 256)");
+constexpr int F2_BWD_SUBS = f2_layout(63, 27).bwd_subs();   // 68
 constexpr int F2_CB_UNSCALE = CB_SCALARS + 4;               // 10 floats: 2^-s of fc_in .. fc_9
 constexpr int F2_CB_SCALE = F2_CB_UNSCALE + 10;             // 10 floats: 2^s
 static_assert(F2_CB_SCALE + 10 <= CONST_FLOATS, "const block");

@@ -216,13 +216,23 @@ __device__ float f16x2_stream_value(const Params &P, const F2Layout &L, int sub,
     return k < E_DIR ? P.w(9, n, FEAT + k) : 0.0f;
 }
 
+// transposed stream (reverse chain): sub-step t of F2Layout::bwd_subs(), image row n = input feature, k-value kk of its k-block
+__device__ float f16x2_bwd_stream_value(const Params &P, int t, int n, int kk, int &layer) {
+    if (t < 4) { layer = 9; return P.w(9, 32 * t + kk, n); }                       // fc_9[:, 0:256]^T: 128 outputs
+    layer = 8 - (t - 4) / 8;
+    const int o = 32 * ((t - 4) % 8) + kk;                                         // output feature of the layer
+    if (layer == 8) return P.w(8, 1 + o, n);                                       // rows 1..256 (row 0: density, vector ALU)
+    if (layer == 5) return P.w(5, o, P.net.e_pos + n);                             // behind the skip connection's position block
+    return P.w(layer, o, n);
+}
+
 __global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
     float *cblock = reinterpret_cast<float *>(out);
     __shared__ float scale[10], unscale[10];
     f16x2_scales(cblock, scale, unscale);
     _Float16 *stream = reinterpret_cast<_Float16 *>(out + CONST_BYTES);
     const F2Layout L = f2_layout(P.net.e_pos, P.net.e_dir);
-    const int64_t n_f16 = (int64_t)L.subs() * F2_SUB_BYTES / 2;
+    const int64_t n_f16 = (int64_t)(L.subs() + L.bwd_subs()) * F2_SUB_BYTES / 2;
     const int64_t total = CONST_FLOATS + n_f16;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
@@ -243,7 +253,8 @@ __global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
         const int64_t r = e - CONST_FLOATS;                    // f16 element index in the stream
         const int sub = (int)(r / (F2_SUB_BYTES / 2));
         const int in_sub = (int)(r % (F2_SUB_BYTES / 2)) * 2;  // byte offset inside the sub-step
-        const int image_bytes = sub >= L.sub_fc9() ? F2_IMAGE_BYTES / 2 : F2_IMAGE_BYTES;
+        const bool reverse = sub >= L.subs();
+        const int image_bytes = (sub >= L.sub_fc9() && !reverse) ? F2_IMAGE_BYTES / 2 : F2_IMAGE_BYTES;
         const int image = in_sub / image_bytes;                // 2 kbi + part (0 hi, 1 lo)
         const int b = in_sub % image_bytes;                    // byte offset inside the image
         const int n = b >> 6;                                  // row (64 B per row)
@@ -251,7 +262,8 @@ __global__ void pack_f16x2_kernel(const Params P, char *__restrict__ out) {
         const int el = (b & 15) >> 1;
         const int kk = 16 * (el >> 2) + 4 * g + (el & 3);
         int layer;
-        const float w = f16x2_stream_value(P, L, sub, image >> 1, n, kk, layer) * scale[layer];
+        const float w = (reverse ? f16x2_bwd_stream_value(P, sub - L.subs(), n, kk, layer)
+                                 : f16x2_stream_value(P, L, sub, image >> 1, n, kk, layer)) * scale[layer];
         const _Float16 hi = (_Float16)w;
         stream[r] = (image & 1) ? (_Float16)(w - (float)hi) : hi;
     }

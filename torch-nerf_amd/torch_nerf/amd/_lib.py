@@ -45,6 +45,7 @@ SIGNATURES = {
     "nerf_mlp_pack_f16x2": (_c_int, [_p, _p, _p, _p]),
     "nerf_mlp_forward_f16x2": (_c_int, [_p, _p, _p, _p, _c_i64, _p, _p, _p]),
     "nerf_mlp_forward_f16x2_record": (_c_int, [_p, _p, _p, _p, _c_i64, _p, _p, _p, _p]),
+    "nerf_mlp_backward_f16x2": (_c_int, [_p, _p, _p, _c_i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_mlp_backward_workspace_bytes": (_c_i64, [_p, _c_i64]),
     "nerf_mlp_backward": (_c_int, [_p, _p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_mlp_layered_record_bytes": (_c_i64, [_p, _c_i64]),

@@ -428,9 +428,11 @@ def mlp_forward_f16x2(packed_f16x2: torch.Tensor, pos: torch.Tensor, view_dir: t
 
 
 def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved, g_sigma, g_rgb,
-                 net: Optional[Net] = None, want_pos: bool = False, want_dir: bool = False):
+                 net: Optional[Net] = None, want_pos: bool = False, want_dir: bool = False, packed_f16x2=None):
     """Parameter gradients as one flat tensor in state_dict order; with want_pos / want_dir -> (g_params, g_pos,
-    g_view_dir): the gradients w.r.t. the ENCODED inputs, (M, pos_dim) / (M, view_dir_dim), None where not asked."""
+    g_view_dir): the gradients w.r.t. the ENCODED inputs, (M, pos_dim) / (M, view_dir_dim), None where not asked.
+    packed_f16x2 (a mlp_pack_f16x2 stream of the same parameters; parameter gradients only): the reverse chain runs on
+    the split-f16 kernel, the dW GEMMs stay fp32."""
     lib = _lib.load()
     M = pos.shape[0]
     g_sigma, g_rgb = _gpu(g_sigma, "g_sigma"), _gpu(g_rgb, "g_rgb")
@@ -440,6 +442,15 @@ def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved,
     g_dir = torch.empty((M, e_d), dtype=torch.float32, device=pos.device) if want_dir else None
     ws_bytes = lib.nerf_mlp_backward_workspace_bytes(_ref(net), M)
     ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=pos.device)
+    if packed_f16x2 is not None and not (want_pos or want_dir):
+        with torch.cuda.device(pos.device):
+            end = _timed("mlp_backward", M)
+            _lib.check(lib.nerf_mlp_backward_f16x2(_ref(net), _ptr(packed), _ptr(packed_f16x2), M, _ptr(sigma), _ptr(rgb),
+                                                   _ptr(saved), _ptr(g_sigma), _ptr(g_rgb), _ptr(g_params), _ptr(ws),
+                                                   _stream()), "nerf_mlp_backward_f16x2")
+            if end is not None:
+                end.record()
+        return g_params
     with torch.cuda.device(pos.device):
         end = _timed("mlp_backward", M)
         _lib.check(lib.nerf_mlp_backward(_ref(net), _ptr(packed), _ptr(flat_params), _ptr(pos), _ptr(view_dir), M,
@@ -490,25 +501,31 @@ class NerfMLPFunction(torch.autograd.Function):
         ctx.shapes = [p.shape for p in params]
         if need_grad:
             pos, view_dir = _gpu(pos, "pos"), _gpu(view_dir, "view_dir")
-            if packed_x2 is not None and not encoded:
+            ctx.f16x2 = packed_x2 is not None and not encoded
+            if ctx.f16x2:
                 sigma, rgb, saved = mlp_forward_f16x2(packed_x2, pos, view_dir, net=net, save=True)
+                ctx.save_for_backward(pos, view_dir, packed, flat_params, sigma, rgb, saved, packed_x2)
             else:
                 sigma, rgb, saved = mlp_forward(packed, pos, view_dir, encoded, save=True, net=net)
-            ctx.save_for_backward(pos, view_dir, packed, flat_params, sigma, rgb, saved)
+                ctx.save_for_backward(pos, view_dir, packed, flat_params, sigma, rgb, saved)
         else:
             sigma, rgb = mlp_forward(packed, pos, view_dir, encoded, save=False, net=net)
         return sigma, rgb
 
     @staticmethod
     def backward(ctx, g_sigma, g_rgb):
-        pos, view_dir, packed, flat_params, sigma, rgb, saved = ctx.saved_tensors
+        packed_x2 = None
+        if ctx.f16x2:
+            pos, view_dir, packed, flat_params, sigma, rgb, saved, packed_x2 = ctx.saved_tensors
+        else:
+            pos, view_dir, packed, flat_params, sigma, rgb, saved = ctx.saved_tensors
         if g_sigma is None:
             g_sigma = torch.zeros_like(sigma)
         if g_rgb is None:
             g_rgb = torch.zeros_like(rgb)
         want_pos, want_dir = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         out = mlp_backward(packed, flat_params, pos, view_dir, ctx.encoded, sigma, rgb, saved,
-                           g_sigma, g_rgb, net=ctx.net, want_pos=want_pos, want_dir=want_dir)
+                           g_sigma, g_rgb, net=ctx.net, want_pos=want_pos, want_dir=want_dir, packed_f16x2=packed_x2)
         g_flat, g_pos, g_dir = out if (want_pos or want_dir) else (out, None, None)
         if not ctx.encoded:    # raw points / directions: through the encoders' reverse pass
             key = (63, 27, 256, 10, 1, 4, 1) if ctx.net is None else ctx.net.key
