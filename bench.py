@@ -179,8 +179,8 @@ def train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank, steps, 
                 "backward": {"ms_per_step": round(bwd_ms / steps, 3), "TFLOPs": round(bwd_tf, 1),
                              "frac": round(bwd_tf / FP32_MFMA_PEAK_TFLOPS, 4)},
                 "other_ms_per_step": round(dt / steps * 1e3 - (fwd_ms + bwd_ms) / steps, 3)}
-    # round 6, opt-in variant: the same step with the RECORDING forward and the reverse chain (dX) on the split-f16 kernels
-    # (NeRF.f16x2_training): two of the step's three thirds at the f16 pipe's rate, the fp32 dW GEMMs behind the same planes
+    # round 6, opt-in variant (NeRF.f16x2_training): the same step with all three thirds on the f16 pipe -- the RECORDING
+    # forward, the reverse chain (dX, one power-of-two scale per sample) and the dW GEMMs (one per gradient plane)
     split = None
     if world == 1:
         for net in nets:
@@ -198,10 +198,12 @@ def train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank, steps, 
         for net in nets:
             net.f16x2_training = False
         fx = [a.elapsed_time(b) for tag, M, a, b in ev if tag == "mlp_forward"]
+        bx = [a.elapsed_time(b) for tag, M, a, b in ev if tag == "mlp_backward"]
         split = {"ms_per_step": dtx / steps * 1e3, "rays_per_s": RAYS * steps / dtx, "speedup_vs_fp32_step": dt / dtx,
-                 "forward_record_ms_per_step": round(sum(fx) / steps, 3),
-                 "what": "NeRF.f16x2_training: record forward AND reverse chain (dX, per-sample power-of-two scale) on the "
-                         "split-f16 kernels, same record and gradient planes; fp32 dW GEMMs + reduction, fused Adam"}
+                 "forward_record_ms_per_step": round(sum(fx) / steps, 3), "backward_ms_per_step": round(sum(bx) / steps, 3),
+                 "what": "NeRF.f16x2_training: record forward, reverse chain (dX, one power-of-two scale per sample) and dW "
+                         "GEMMs (one per gradient plane) on the split-f16 kernels; same record, gradient planes, partial "
+                         "tiles and fixed-order reduction as the fp32 step, fp32 accumulation, fused Adam"}
     return {"rays_per_s": world * RAYS * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "f16x2_training": split,
             "what": "fwd+bwd+fused Adam+ExponentialLR, both networks, 4096 rays x (64 + 192) samples per GPU"
                     + (f", gradient all-reduce over {world} ranks" if world > 1 else ""),

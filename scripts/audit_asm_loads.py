@@ -38,6 +38,8 @@ ASM_MNEMONICS = {
     "v_pk_max_i16": ("mfma-d",),
     # split-f16 kernel (mlp_forward_f16x2.hip): range tracking and the hand-written hi / lo split
     "v_max3_f32": ("mfma-d",), "v_cvt_pk_f16_f32": ("mfma-d",), "v_fma_mix_f32": ("mfma-d",),
+    # reverse chain of the split-f16 kernel: the workgroup's per-plane |dY| maxima (LDS atomic, no return value)
+    "ds_max_u32": ("mfma-d",),
 }
 MFMA_WAIT_STATES = 18
 

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--f16x2-training", action="store_true", help="record forward of every step on the split-f16 kernel "
-                    "(NeRF.f16x2_training, round 6); the backward stays the fp32 kernels")
+                    "and its backward on the split-f16 kernels (NeRF.f16x2_training, round 6)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "train_proc"))
     args = ap.parse_args()
 

@@ -686,21 +686,293 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_list_kernel(const GemmList 
     dw_main<true>(items, list->n, list->work_total, nullptr, nullptr, partial, M, lds, list->side_h9 ? list : nullptr);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// stage 2 on the f16 matrix pipe (NeRF.f16x2_training): dW_l = dY_l^T X_l with both operands split in two f16 parts
+// ------------------------------------------------------------------------------------------
+// Same items, same work partition, same partial-tile format and the same reduction as mlp_bwd_dw_kernel; what changes is
+// the inner loop: a 32-sample tile is two k-steps of v_mfma_f32_32x32x16_f16 (16 samples each) instead of sixteen of
+// 32x32x2.  An operand fragment is one feature over 8 consecutive samples: eight ds_read_b32 out of the TF-layout tile (the
+// XOR of that layout moves a lane's samples around inside a 256-byte run: eight per-lane offsets, computed once), split
+// in registers (v_cvt_pk_f16_f32, the residual as one v_fma_mix_f32, v_cvt_pk_f16_f32) and fed to lo.hi + hi.lo + hi.hi.
+// The sum runs OVER samples, so dY cannot carry a scale per sample here: it takes ONE power of two per gradient plane, from
+// the plane's largest |dY| that the split reverse chain leaves behind (atomicMax, order-independent).  A sample whose
+// gradient is 2^15 below the largest is carried to fewer bits -- and weighs 2^-15 in the sum: the error stays below the
+// fp32 rounding of the sum (tests/test_gpu_f16x2.py drives eight decades).  X (activations, encodings) is O(1): unscaled.
+// The two thin side rows (density row of fc_8, fc_out) are a separate pass here (fused_thin_kernel).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+struct ItemPlanes { signed char p[MAX_GEMMS]; };   // which gradient plane (0..8 = dY0..dY8, 9 = dY9) an item's dY window is
+
+__device__ __forceinline__ void split8(const float (&v)[8], h16x8 &hi, h16x8 &lo) {
+    unsigned H[4], L[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r0, r1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(H[j]) : "v"(v[2 * j]), "v"(v[2 * j + 1]));
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v[2 * j]), "v"(H[j]));
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v[2 * j + 1]), "v"(H[j]));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(L[j]) : "v"(r0), "v"(r1));
+    }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 hv = {H[0], H[1], H[2], H[3]}, lv = {L[0], L[1], L[2], L[3]};
+    hi = __builtin_bit_cast(h16x8, hv);
+    lo = __builtin_bit_cast(h16x8, lv);
+}
+
+template <int NA, int KB>
+__device__ __forceinline__ void dw_body_x2(const GemmDesc &g, int slice, int64_t t0, int64_t t1, float *__restrict__ partial,
+                                           char *lds, int lane, int wave, float gscale) {
+    constexpr int AW = 128 * NA, XW = 32 * KB;
+    constexpr int A_PIECES = 32 * AW * 4 / 1024 / 4, X_PIECES = 32 * XW * 4 / 1024 / 4;   // 1-KiB DMA pieces per wave
+    constexpr int A_BYTES = 32 * AW * 4, X_BYTES = 32 * XW * 4, STAGE_BYTES = A_BYTES + X_BYTES;
+    constexpr int NSTAGE = (KB <= 2) ? 3 : 2;
+    // KB = 1 (the 128 x 32 direction item: six MFMAs per tile) issues the next tile's five pieces in one go behind the
+    // barrier.  Spread between the k-steps like the wider shapes, this one shape came back with wrong fc_9 direction columns
+    // on gfx950 -- the same wrong values with two and three stages and with a pause behind the barrier, right again with the
+    // pieces in front of or behind the k-steps; the ISA's addresses and waits check out and the cause was not found
+    // (scripts/diag_f16x2_dw.py is the check that caught it; tests/test_gpu_f16x2.py compares every tensor's entries).
+    constexpr bool FRONT = KB == 1;
+    constexpr int PER_WAVE = A_PIECES + X_PIECES, SLOTS = 2 * KB, PPS = (PER_WAVE + SLOTS - 1) / SLOTS;
+    static_assert(NSTAGE * STAGE_BYTES <= DW_LDS_BYTES, "stage ring exceeds the LDS allocation");
+    static_assert((NSTAGE - 2) * PER_WAVE < 64, "counted wait");
+    const int i = lane & 31, kg = lane >> 5;
+    const bool want_bias = (g.flags & FLAG_BIAS) != 0;
+    const char *a_src = g.a_src, *x_src = g.x_src;
+    const int64_t a_stride = g.a_stride, x_stride = g.x_stride;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    float *out = partial + g.partial_off + slice * slice_stride(g);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    // feature 32 blk + i of sample s inside a TF tile: byte blk * 4096 + 1024 q + ((32 s + 16 hh) ^ (32 q)) + 4 e with
+    // q = (i >> 3) & 3, hh = (i >> 2) & 1, e = i & 3; this lane's samples of k-step ks are 16 ks + 8 kg + j, j = 0..7
+    const unsigned q = (unsigned)(i >> 3) & 3u, hh = (unsigned)(i >> 2) & 1u, e = (unsigned)i & 3u;
+    unsigned off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) off[j] = 1024u * q + 256u * (unsigned)kg + 16u * hh + 4u * e + 32u * ((unsigned)j ^ q);
+
+    f32x16 acc[NA][KB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float bsum[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) bsum[a] = 0.0f;
+
+    auto issue_piece = [&](int64_t t, int buf, int j) {
+        const unsigned ad = lds_base + buf * STAGE_BYTES;
+        if (j < A_PIECES) lds_dma_16s(a_src + t * a_stride + (wave + 4 * j) * 1024, lane_off, ad + (wave + 4 * j) * 1024);
+        else {
+            const int jx = j - A_PIECES;
+            lds_dma_16s(x_src + t * x_stride + (wave + 4 * jx) * 1024, lane_off, ad + A_BYTES + (wave + 4 * jx) * 1024);
+        }
+    };
+    if (t0 < t1)
+        for (int d = 0; d < NSTAGE - 1; ++d) {
+            const int64_t tt = t0 + d < t1 ? t0 + d : t1 - 1;
+#pragma unroll
+            for (int j = 0; j < PER_WAVE; ++j) issue_piece(tt, d, j);
+        }
+    int buf = 0;
+    for (int64_t t = t0; t < t1; ++t) {
+        wait_vmcnt<(NSTAGE - 2) * PER_WAVE>();   // tile t landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();            // ... and everybody else's; stage (t-1) is free again
+        asm volatile("" ::: "memory");
+        const int64_t tn_raw = t + NSTAGE - 1;
+        const int64_t tn = tn_raw < t1 ? tn_raw : t1 - 1;
+        int nbuf = buf + NSTAGE - 1;
+        if (nbuf >= NSTAGE) nbuf -= NSTAGE;
+        const char *stage = lds + buf * STAGE_BYTES;
+        if (FRONT) {
+#pragma unroll
+            for (int j = 0; j < PER_WAVE; ++j) issue_piece(tn, nbuf, j);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h16x8 ahi[NA], alo[NA];
+#pragma unroll
+            for (int nb = 0; nb < NA; ++nb) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = *reinterpret_cast<const float *>(stage + (wave * NA + nb) * 4096 + 512 * ks + off[j]);
+                bsum[nb] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= gscale;
+                split8(v, ahi[nb], alo[nb]);
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = *reinterpret_cast<const float *>(stage + A_BYTES + kb * 4096 + 512 * ks + off[j]);
+                h16x8 bhi, blo;
+                split8(v, bhi, blo);
+#pragma unroll
+                for (int p = 0; p < PPS; ++p)
+                    if (!FRONT && (ks * KB + kb) * PPS + p < PER_WAVE) issue_piece(tn, nbuf, (ks * KB + kb) * PPS + p);
+#pragma unroll
+                for (int nb = 0; nb < NA; ++nb) {
+                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[nb], bhi, acc[nb][kb], 0, 0, 0);
+                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[nb], blo, acc[nb][kb], 0, 0, 0);
+                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[nb], bhi, acc[nb][kb], 0, 0, 0);
+                }
+            }
+        }
+        buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+    }
+    // partial tile of this slice, the layout of dw_body: row-major [AW][XW], then bias[AW]
+    // (the accumulators go out as they are, 2^t too large: the reducer takes the scale out of the slices' sum, which keeps
+    // this flush a run of stores straight from the accumulation registers)
+    {
+        const unsigned lane_bytes = (unsigned)(4 * kg * XW + i) * 4u;
+#pragma unroll
+        for (int nb = 0; nb < NA; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *row = out + (int64_t)(wave * 32 * NA + 32 * nb + (r & 3) + 8 * (r >> 2)) * XW;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(row) + lane_bytes + kb * 128) = acc[nb][kb][r];
+            }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NA; ++nb) {
+        const float both = bsum[nb] + __shfl_xor(bsum[nb], 32, WAVE);
+        if (want_bias && kg == 0) out[AW * XW + wave * 32 * NA + 32 * nb + i] = both;
+    }
+}
+
+// 2^t that takes a gradient plane's largest |dY| into [2^9, 2^10) (1 for an all-zero or non-finite plane)
+__device__ __forceinline__ float plane_scale(const unsigned *__restrict__ plane_max, int plane, bool inverse) {
+    const float mx = __builtin_bit_cast(float, plane_max[plane]);
+    int ex;
+    (void)frexpf(mx, &ex);
+    int tt = 10 - ex;
+    tt = tt > 100 ? 100 : (tt < -100 ? -100 : tt);
+    return (mx > 0.0f && mx < INFINITY) ? ldexpf(1.0f, inverse ? -tt : tt) : 1.0f;
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_bwd_dw_x2_kernel(GemmTable table, float *__restrict__ partial, int64_t M,
+                                                                const unsigned *__restrict__ plane_max, ItemPlanes planes) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t MP = padded_rows(M), tiles = MP / 32;
+    const int64_t B = gridDim.x, b = blockIdx.x;
+    const int64_t lo = table.work_total * b / B, hi = table.work_total * (b + 1) / B;
+    bool first = true;
+    for (int k = 0; k < table.n; ++k) {
+        const GemmDesc &g = table.g[k];
+        const int slice = (int)b - g.first_block;
+        if (slice < 0 || slice >= g.num_slices) continue;
+        auto tile_at = [&](int64_t unit) {
+            const int64_t rel = unit - g.unit_off;
+            const int64_t j = rel <= 0 ? 0 : (rel + g.cost - 1) / g.cost;
+            return j < tiles ? j : tiles;
+        };
+        const int64_t t0 = tile_at(lo), t1 = tile_at(hi);
+        if (!first) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        first = false;
+        const float gscale = plane_scale(plane_max, planes.p[k], false);
+        if (g.a_width == 256 && g.x_width == 256) dw_body_x2<2, 8>(g, slice, t0, t1, partial, lds, lane, wave, gscale);
+        else if (g.a_width == 256 && g.x_width == 64) dw_body_x2<2, 2>(g, slice, t0, t1, partial, lds, lane, wave, gscale);
+        else if (g.a_width == 128 && g.x_width == 256) dw_body_x2<1, 8>(g, slice, t0, t1, partial, lds, lane, wave, gscale);
+        else dw_body_x2<1, 1>(g, slice, t0, t1, partial, lds, lane, wave, gscale);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// the two thin rows the fp32 dW kernel sums as side jobs: fc_8.weight[0, :] = sum_m dsig[m] h7[m, :] and fc_out.weight[c, :] =
+// sum_m gy[m][c] h9[m, :] -- one pass over the h7 / h9 planes of the record (HBM-bound), double accumulation, fixed order
+constexpr int X2_THIN_SLICES = 512;
+__global__ __launch_bounds__(64) void fused_thin_kernel(const float *__restrict__ saved, const float *__restrict__ dy, int64_t MP,
+                                                        int slices, double *__restrict__ partial) {
+    const int blk = blockIdx.x, lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const bool is_h7 = blk < 8;
+    const int fb = is_h7 ? blk : blk - 8, width = is_h7 ? 256 : 128;
+    const float *plane = saved + (is_h7 ? pl_h(MP, 7) : pl_h9(MP));
+    const float *gy = dy + gy_plane(MP), *ds = dy + dsig_plane(MP);
+    const int64_t tiles = MP / 32, per = (tiles + slices - 1) / slices;
+    const int64_t t0 = blockIdx.y * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+    double acc[3][16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+        const float *tile = plane + t * 32 * width + fb * 1024;
+        const int64_t m = t * 32 + i;
+        float x[16];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + qq * 256 + 4 * ((2 * i + h) ^ (2 * qq)));
+            x[4 * qq] = v.x; x[4 * qq + 1] = v.y; x[4 * qq + 2] = v.z; x[4 * qq + 3] = v.w;
+        }
+        if (is_h7) {
+            const double gd = (double)ds[m];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] += gd * (double)x[r];
+        } else {
+            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gy + 4 * m);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[0][r] += (double)g4.x * (double)x[r];
+                acc[1][r] += (double)g4.y * (double)x[r];
+                acc[2][r] += (double)g4.z * (double)x[r];
+            }
+        }
+    }
+    double *out = partial + (int64_t)blockIdx.y * (256 + 3 * 128);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (is_h7 && c > 0) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double v = acc[c][r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);      // over the 32 samples of this lane half
+            const int k = 32 * fb + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (i == 0) out[is_h7 ? k : 256 + c * 128 + k] = v;
+        }
+    }
+}
+__global__ __launch_bounds__(64) void fused_thin_reduce_kernel(const double *__restrict__ partial, int slices, float *__restrict__ g_params,
+                                                               int64_t off_w8, int64_t off_wout) {
+    const int col = blockIdx.x;     // 0..255 density row, 256..639 fc_out.weight (3 x 128, contiguous)
+    __shared__ double part[64];
+    double acc = 0.0;
+    for (int z = threadIdx.x; z < slices; z += 64) acc += partial[(int64_t)z * 640 + col];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int t = 1; t < 64; ++t) acc += part[t];
+    g_params[col < 256 ? off_w8 + col : off_wout + (col - 256)] = (float)acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // stage 3: reduce partial tiles into the flat gradient (state_dict layout), fixed order
 // ------------------------------------------------------------------------------------------
+template <bool SCALED>
 __device__ __forceinline__ void reduce_item(const GemmDesc &g, const float *__restrict__ partial, int64_t off_wout,
-                                            float *__restrict__ g_params);
+                                            float *__restrict__ g_params, float tile_scale);
 
 __global__ void mlp_bwd_reduce_list_kernel(const GemmList *__restrict__ list, const float *__restrict__ partial,
                                            float *__restrict__ g_params) {
     const GemmDesc *items = reinterpret_cast<const GemmDesc *>(list + 1);
-    if ((int)blockIdx.y < list->n) reduce_item(items[blockIdx.y], partial, list->off_wout, g_params);
+    if ((int)blockIdx.y < list->n) reduce_item<false>(items[blockIdx.y], partial, list->off_wout, g_params, 1.0f);
 }
 
-__global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__ partial,
-                                      const float *__restrict__ bias_partial, int bias_partials,
-                                      float *__restrict__ g_params) {
+template <bool SCALED>
+__device__ __forceinline__ void reduce_main(const GemmTable &table, const float *__restrict__ partial,
+                                            const float *__restrict__ bias_partial, int bias_partials,
+                                            float *__restrict__ g_params, const unsigned *__restrict__ plane_max,
+                                            const ItemPlanes *planes) {
     const int gi = blockIdx.y;
     if (gi >= table.n) {  // the four scalar-output bias gradients: per-wavefront partials of the dX chain, fixed order
         __shared__ float part[64][4];
@@ -717,11 +989,28 @@ __global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__
         }
         return;
     }
-    reduce_item(table.g[gi], partial, table.off_wout, g_params);
+    reduce_item<SCALED>(table.g[gi], partial, table.off_wout, g_params,
+                        SCALED ? plane_scale(plane_max, planes->p[gi], true) : 1.0f);
 }
 
+__global__ void mlp_bwd_reduce_kernel(GemmTable table, const float *__restrict__ partial,
+                                      const float *__restrict__ bias_partial, int bias_partials,
+                                      float *__restrict__ g_params) {
+    reduce_main<false>(table, partial, bias_partial, bias_partials, g_params, nullptr, nullptr);
+}
+
+// after mlp_bwd_dw_x2_kernel: every item's weight entries come back out of its gradient plane's power-of-two scale
+__global__ void mlp_bwd_reduce_x2_kernel(GemmTable table, const float *__restrict__ partial,
+                                         const float *__restrict__ bias_partial, int bias_partials,
+                                         float *__restrict__ g_params, const unsigned *__restrict__ plane_max,
+                                         ItemPlanes planes) {
+    reduce_main<true>(table, partial, bias_partial, bias_partials, g_params, plane_max, &planes);
+}
+
+// SCALED (the split-f16 dW kernel's partial tiles): the weight entries leave multiplied by tile_scale, a power of two
+template <bool SCALED>
 __device__ __forceinline__ void reduce_item(const GemmDesc &g, const float *__restrict__ partial, int64_t off_wout,
-                                            float *__restrict__ g_params) {
+                                            float *__restrict__ g_params, float tile_scale) {
     const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     const float *base = partial + g.partial_off;
@@ -769,7 +1058,7 @@ __device__ __forceinline__ void reduce_item(const GemmDesc &g, const float *__re
             s += p0; s += p1; s += p2; s += p3;
         }
         for (; sl < g.num_slices; ++sl) s += base[(int64_t)sl * stride + src];
-        g_params[dst] = s;
+        g_params[dst] = (SCALED && e < tile) ? s * tile_scale : s;
     }
 }
 
@@ -1063,11 +1352,13 @@ NERF_API int64_t nerf_mlp_backward_workspace_bytes(const nerf_net_t *net, int64_
 
 namespace nerf {   // mlp_forward_f16x2.hip: stage 1 on the split-f16 kernel
 int launch_dx_f16x2(const void *packed_f16x2, int64_t M, const float *sigma, const float *rgb, const float *g_sigma,
-                    const float *g_rgb, const float *saved, float *dy, float *bias_partial, int *partials, hipStream_t s);
+                    const float *g_rgb, const float *saved, float *dy, float *bias_partial, int *partials, unsigned *plane_max,
+                    hipStream_t s);
 }
 
 // packed_f16x2 != NULL (and no input gradients asked for): stage 1, the reverse chain, runs on the split-f16 kernel; the
-// dW GEMMs and the reduction are the same fp32 kernels over the same planes
+// dW GEMMs run on the f16 pipe too (mlp_bwd_dw_x2_kernel: same items, work partition and partial-tile format), the two thin
+// side rows in a pass of their own, and the reduction takes the gradient planes' power-of-two scales out again
 static int backward_impl(const nerf_net_t *net_abi, const void *packed, const void *packed_f16x2, int64_t M, const float *sigma,
                          const float *rgb, const void *saved, const float *g_sigma, const float *g_rgb,
                          float *g_params, float *g_pos, float *g_view_dir, void *workspace,
@@ -1105,8 +1396,15 @@ static int backward_impl(const nerf_net_t *net_abi, const void *packed, const vo
     const unsigned dx_grid = (unsigned)(ntiles < cus ? ntiles : (cus < 1024 ? cus : 1024));
     int bias_partials = (int)dx_grid * 4;
     int rc;
-    if (packed_f16x2 && !input_grads) {
-        rc = nerf::launch_dx_f16x2(packed_f16x2, M, sigma, rgb, g_sigma, g_rgb, sv, dy, bias_partial, &bias_partials, s);
+    const bool split = packed_f16x2 && !input_grads;
+    // (split path: 16 words of per-plane |dY| maxima + the thin rows' partial sums live behind the bias partials -- inside the
+    // workspace: its partial-tile area is sized for 2 x 256 + 13 slices, a plan uses at most cus + 12)
+    unsigned *plane_max = reinterpret_cast<unsigned *>(bias_partial + BIAS_PARTIAL_FLOATS);
+    double *thin_partial = reinterpret_cast<double *>(bias_partial + BIAS_PARTIAL_FLOATS + 64);
+    if (split) {
+        NERF_REQUIRE(cus <= 384, "nerf_mlp_backward_f16x2: workspace layout assumes at most 384 compute units");
+        if (hipMemsetAsync(plane_max, 0, 64, s) != hipSuccess) return nerf::check_launch("nerf_mlp_backward_f16x2: memset");
+        rc = nerf::launch_dx_f16x2(packed_f16x2, M, sigma, rgb, g_sigma, g_rgb, sv, dy, bias_partial, &bias_partials, plane_max, s);
     } else {
         hipLaunchKernelGGL(dx_kernel, dim3(dx_grid), dim3(256), mlp::LDS_BYTES, s,
                            static_cast<const char *>(packed), M, sigma, rgb, g_sigma, g_rgb, sv, dy, bias_partial);
@@ -1123,6 +1421,28 @@ static int backward_impl(const nerf_net_t *net_abi, const void *packed, const vo
     const char *timing_path = getenv("NERF_DW_TIMING");
     unsigned long long *clocks = nullptr;
     if (timing_path && hipMalloc(&clocks, sizeof(unsigned long long) * plan.total_blocks) != hipSuccess) clocks = nullptr;
+    if (split) {
+        static nerf::DeviceMask configured_x2{0};
+        if (int rc2 = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_dw_x2_kernel), DW_LDS_BYTES, configured_x2,
+                                               "nerf_mlp_backward_f16x2: LDS attribute (dW)"))
+            return rc2;
+        GemmTable tx = plan.table;             // same items and work partition; the two side rows go to the thin pass
+        ItemPlanes planes;
+        static const signed char item_plane[12] = {0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 9};     // make_plan's order
+        for (int k = 0; k < tx.n; ++k) { tx.g[k].flags &= FLAG_BIAS; planes.p[k] = item_plane[k]; }
+        hipLaunchKernelGGL(mlp_bwd_dw_x2_kernel, dim3((unsigned)plan.total_blocks), dim3(256), DW_LDS_BYTES, s, tx, partial, M,
+                           static_cast<const unsigned *>(plane_max), planes);
+        if ((rc = nerf::check_launch("nerf_mlp_backward_f16x2: dW")) != NERF_OK) return rc;
+        int slices = (int)(MP / 32 / 8);
+        slices = slices > X2_THIN_SLICES ? X2_THIN_SLICES : (slices < 1 ? 1 : slices);
+        hipLaunchKernelGGL(fused_thin_kernel, dim3(12, slices), dim3(64), 0, s, sv, static_cast<const float *>(dy), MP, slices, thin_partial);
+        hipLaunchKernelGGL(mlp_bwd_reduce_x2_kernel, dim3(256, tx.n + 1), dim3(256), 0, s, tx,
+                           static_cast<const float *>(partial), static_cast<const float *>(bias_partial), bias_partials, g_params,
+                           static_cast<const unsigned *>(plane_max), planes);
+        hipLaunchKernelGGL(fused_thin_reduce_kernel, dim3(640), dim3(64), 0, s, static_cast<const double *>(thin_partial), slices,
+                           g_params, (int64_t)net.w_offset(8), (int64_t)net.w_offset(10));
+        return nerf::check_launch("nerf_mlp_backward_f16x2: reduce");
+    }
     hipLaunchKernelGGL(mlp_bwd_dw_kernel, dim3((unsigned)plan.total_blocks), dim3(256), DW_LDS_BYTES, s,
                        plan.table, sv, static_cast<const float *>(dy), partial, M, clocks);
     rc = nerf::check_launch("nerf_mlp_backward: dW");

@@ -516,16 +516,25 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_forward_f16x2_kernel(const 
 // ---------------------------------------------------------------------------------------------------------------------
 // The reverse chain (dX) on the split kernel: dY^T(l-1) = W_l^T dY^T(l), the fused family's mlp_bwd_dx_kernel (mlp_backward.hip)
 // with split operands.  Same inputs (the forward's record: ReLU bit planes; sigma, rgb, their gradients), same outputs (the
-// gradient planes dY0..dY8, dY9, dsig, gy in the workspace the fp32 dW kernel reads; per-wavefront sums of the four scalar
+// gradient planes dY0..dY8, dY9, dsig, gy in the workspace the dW kernels read; per-wavefront sums of the four scalar
 // bias gradients).
 // Gradients are not O(1) like activations: a sample's dY can sit at 1e-7, where f16 has no bits left.  Samples are the
 // COLUMNS of these MFMAs, so every sample carries its own power-of-two scale: before a layer's dY is split it is multiplied
 // by 2^t with t chosen from the sample's largest |dY| (-> [2^9, 2^10)), and the seam behind the contraction divides it out
 // again (exact) before the plane store.  Within a column, elements below 2^-22 of its largest lose relative precision --
 // they are below the fp32 rounding of the sums they enter.
-__device__ __forceinline__ float column_scale(float amax_lane) {
+// `plane_word` (0 = none): LDS byte address of the workgroup's running largest |dY| of this gradient plane, for the split-f16 dW
+// GEMMs (mlp_backward.hip: they reduce OVER samples and take ONE scale per plane).  ds_max_u32 on the bit pattern of a
+// non-negative float -- an LDS atomic (lgkmcnt), NOT a global one: one global atomic per wavefront and layer is 10 x M / 16
+// returns to ten addresses of one L2 line (+3 ms at 1 M samples) and one more vmcnt event than SubPipe's counted waits know.
+__device__ __forceinline__ float column_scale(float amax_lane, unsigned plane_word = 0) {
     float a = fmaxf(amax_lane, __shfl_xor(amax_lane, 16, WAVE));
     a = fmaxf(a, __shfl_xor(a, 32, WAVE));
+    if (plane_word) {
+        // lane group 0 holds the 16 samples' maxima; +inf / NaN (a poisoned forward) stay out: the scale falls back to 1
+        if ((threadIdx.x & 48) == 0 && a < INFINITY)
+            asm volatile("ds_max_u32 %0, %1" : : "v"(plane_word), "v"(__builtin_bit_cast(unsigned, a)) : "memory");
+    }
     int e;
     (void)frexpf(a, &e);                       // a = f 2^e, f in [0.5, 1)
     int t = 10 - e;
@@ -540,7 +549,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_bwd_dx_f16x2_kernel(const c
                                                                           const float *__restrict__ g_rgb,
                                                                           const float *__restrict__ saved,
                                                                           float *__restrict__ dy,
-                                                                          float *__restrict__ bias_partial) {
+                                                                          float *__restrict__ bias_partial,
+                                                                          unsigned *__restrict__ plane_max) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -548,9 +558,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_bwd_dx_f16x2_kernel(const c
     const int n = lane & 15, g = lane >> 4;
     float *cb_ = reinterpret_cast<float *>(lds);
     const unsigned ring = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)CONST_BYTES;
-    for (int e = tid; e < CONST_FLOATS / 4; e += 64 * WAVES)
-        reinterpret_cast<f32x4 *>(cb_)[e] = reinterpret_cast<const f32x4 *>(packed)[e];
+    for (int e = tid; e < CONST_FLOATS / 4; e += 64 * WAVES) {
+        f32x4 v = reinterpret_cast<const f32x4 *>(packed)[e];
+        if (e >= F2_CB_PLANE_MAX / 4) v = f32x4{0.f, 0.f, 0.f, 0.f};      // the workgroup's plane maxima start at zero
+        reinterpret_cast<f32x4 *>(cb_)[e] = v;
+    }
     const unsigned frag = ring + (unsigned)f2_frag_offset(n, g);
+    const unsigned plane_words = plane_max ? (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + 4u * F2_CB_PLANE_MAX : 0u;
 
     SubPipe pipe;
     pipe.src_wave = packed + CONST_BYTES + (int64_t)F2_SUBS * SUB_BYTES + wave * (PIECES * 1024);   // the transposed stream
@@ -630,7 +644,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_bwd_dx_f16x2_kernel(const c
             return v;
         };
         // NB blocks of dY held in acc[] (true values) -> packed hi / lo of dY * 2^t; returns 2^-t
-        auto scale_and_split = [&](auto nb_tag) {
+        auto scale_and_split = [&](auto nb_tag, int plane) {
             constexpr int NB = decltype(nb_tag)::value;
             float amax = 0.0f;
 #pragma unroll
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_bwd_dx_f16x2_kernel(const c
                 asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(acc[fb][0]), "v"(acc[fb][1]));
                 asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(acc[fb][2]), "v"(acc[fb][3]));
             }
-            const float cs = column_scale(amax);
+            const float cs = column_scale(amax, plane_words ? plane_words + 4u * (unsigned)plane : 0u);
 #pragma unroll
             for (int fb = 0; fb < NB; ++fb) {
                 const f32x4 x = acc[fb] * cs;
@@ -663,7 +677,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_bwd_dx_f16x2_kernel(const c
             acc[fb] = masked4(mk, fb, v);
             rec.store(dy9_plane(MP), 128, fb, acc[fb], pipe);
         }
-        float inv_cs = scale_and_split(Eight());
+        float inv_cs = scale_and_split(Eight(), 9);
         u32x4 mk_next = load_mask(7);
         // ---- d y8[1:257] = W9[:, 0:256]^T dY9: four sub-steps, accumulators from zero
 #pragma unroll
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_bwd_dx_f16x2_kernel(const c
             }
             if (l > 1) mk_next = load_mask(l == 8 ? 7 : l - 1);      // (l = 8 uses none: h7's bits serve the seam of l = 7)
             else mk_next = load_mask(0);
-            inv_cs = scale_and_split(Sixteen());
+            inv_cs = scale_and_split(Sixteen(), l);
             if (l == 8) {      // the density row of fc_8 contributes w8[0, k] * d y8[0]: into the (scaled) accumulators
                 const float init = dsig * cb_[F2_CB_SCALE + 8] / inv_cs;
 #pragma unroll
@@ -709,11 +723,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_bwd_dx_f16x2_kernel(const c
         // ---- dY0: mask with h0 and store (the encodings carry no gradient)
         {
             const float un = cb_[F2_CB_UNSCALE + 1] * inv_cs;
+            float amax0 = 0.0f;
 #pragma unroll
             for (int fb = 0; fb < 16; ++fb) {
                 const f32x4 x = masked4(mk_next, fb, acc[fb] * un);
                 rec.store(dy_plane(MP, 0), 256, fb, x, pipe);
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax0) : "v"(x[0]), "v"(x[1]));
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax0) : "v"(x[2]), "v"(x[3]));
             }
+            if (plane_words) (void)column_scale(amax0, plane_words);
         }
     }
 #pragma unroll
@@ -723,7 +741,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_bwd_dx_f16x2_kernel(const c
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
         if (lane == 0) bias_partial[((int64_t)blockIdx.x * WAVES + wave) * 4 + c] = v;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (plane_max) {      // the workgroup's ten maxima into the launch's (order-independent)
+        __syncthreads();
+        if (tid < 10) {
+            const unsigned w = reinterpret_cast<const unsigned *>(cb_)[F2_CB_PLANE_MAX + tid];
+            if (w) atomicMax(plane_max + tid, w);
+        }
+    }
 }
 
 }  // namespace
@@ -786,7 +811,8 @@ NERF_API int nerf_mlp_forward_f16x2_record(const nerf_net_t *net_abi, const void
 // on the f16 matrix pipe; `partials` = number of per-wavefront bias partials written (the reducer's loop bound)
 namespace nerf {
 int launch_dx_f16x2(const void *packed_f16x2, int64_t M, const float *sigma, const float *rgb, const float *g_sigma,
-                    const float *g_rgb, const float *saved, float *dy, float *bias_partial, int *partials, hipStream_t s) {
+                    const float *g_rgb, const float *saved, float *dy, float *bias_partial, int *partials, unsigned *plane_max,
+                    hipStream_t s) {
     static nerf::DeviceMask configured = {0};
     if (int rc = nerf::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_dx_f16x2_kernel), F2_LDS_BYTES, configured,
                                           "nerf_mlp_backward_f16x2: LDS attribute (dX)"))
@@ -795,7 +821,7 @@ int launch_dx_f16x2(const void *packed_f16x2, int64_t M, const float *sigma, con
     const int64_t ntiles = mlp::padded_rows(M) / TILE;
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : (cus < 512 ? cus : 512));
     hipLaunchKernelGGL(mlp_bwd_dx_f16x2_kernel, dim3(grid), dim3(64 * WAVES), F2_LDS_BYTES, s,
-                       static_cast<const char *>(packed_f16x2), M, sigma, rgb, g_sigma, g_rgb, saved, dy, bias_partial);
+                       static_cast<const char *>(packed_f16x2), M, sigma, rgb, g_sigma, g_rgb, saved, dy, bias_partial, plane_max);
     *partials = (int)grid * WAVES;
     return nerf::check_launch("nerf_mlp_backward_f16x2: dx chain");
 }

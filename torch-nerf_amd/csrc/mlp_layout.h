@@ -242,6 +242,9 @@ constexpr int F2_BWD_SUBS = f2_layout(63, 27).bwd_subs();   // 68
 constexpr int F2_CB_UNSCALE = CB_SCALARS + 4;               // 10 floats: 2^-s of fc_in .. fc_9
 constexpr int F2_CB_SCALE = F2_CB_UNSCALE + 10;             // 10 floats: 2^s
 static_assert(F2_CB_SCALE + 10 <= CONST_FLOATS, "const block");
+// (the packer's 10 x 16 partial maxima follow, mlp_pack.hip) ... and the last 16 words are, in the LDS copy of the reverse
+// chain, the workgroup's running maxima of |dY| per gradient plane (mlp_forward_f16x2.hip: ds_max_u32, flushed at the end)
+constexpr int F2_CB_PLANE_MAX = CONST_FLOATS - 16;
 constexpr int64_t F2_PACKED_BYTES = f2_layout(63, 27).packed_bytes();
 __host__ __device__ constexpr int f2_sigma(int q) { return (0x78 >> (2 * q)) & 3; }     // 0, 2, 3, 1
 __host__ __device__ constexpr int f2_frag_offset(int n, int g) { return n * 64 + ((g ^ f2_sigma((n >> 2) & 3)) << 4); }

@@ -160,7 +160,7 @@ __global__ void pack_bf16_kernel(const Params P, char *__restrict__ out) {
 // const block's spare floats, and every block of the pack kernel folds the 160 partials into its own copy of the scales.
 constexpr int F2_SLICES = 16;
 constexpr int F2_CB_PARTIAL = F2_CB_SCALE + 10;     // 10 x F2_SLICES floats
-static_assert(F2_CB_PARTIAL + 10 * F2_SLICES <= CONST_FLOATS, "const block");
+static_assert(F2_CB_PARTIAL + 10 * F2_SLICES <= F2_CB_PLANE_MAX, "const block");
 
 __global__ __launch_bounds__(256) void f16x2_absmax_kernel(const Params P, float *__restrict__ cblock) {
     const int l = blockIdx.y, slice = blockIdx.x;
