@@ -1,8 +1,9 @@
 """Backward of one launch, fp32 kernels vs NeRF.f16x2_training's split-f16 kernels, at the bench's two launch sizes.
 Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
+import os
 import sys
 import torch
-sys.path.insert(0, "torch-nerf_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "torch-nerf_amd"))
 from torch_nerf.amd import ops, synth
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 flat = torch.from_numpy(synth.nerf_flat_params(seed=3, sigma_bias=1.0, sigma_gain=30.0)).cuda()

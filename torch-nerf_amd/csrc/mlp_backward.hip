@@ -788,37 +788,70 @@ __device__ __forceinline__ void dw_body_x2(const GemmDesc &g, int slice, int64_t
 #pragma unroll
             for (int j = 0; j < PER_WAVE; ++j) issue_piece(tn, nbuf, j);
         }
+        // Two k-steps x KB column blocks = 2 KB steps, software-pipelined by hand: step s issues the LDS reads of step
+        // s + 1's X fragment first, then its own MFMAs, and splits that fragment in their shadow (a pair of samples = four
+        // vector instructions between two MFMAs; sched_barrier pins the order -- left to itself the compiler splits first and
+        // the matrix pipe waits out every LDS round trip: 12.4 k clocks per 256 x 256 tile instead of ~4 k).
+        constexpr int STEPS = 2 * KB;
+        auto read_x = [&](int st, float (&r)[8]) {
+            const int ks = st / KB, kb = st % KB;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            h16x8 ahi[NA], alo[NA];
+            for (int jj = 0; jj < 8; ++jj)
+                r[jj] = *reinterpret_cast<const float *>(stage + A_BYTES + kb * 4096 + 512 * ks + off[jj]);
+        };
+        h16x8 ahi[NA], alo[NA];
+        auto load_a = [&](int ks) {
 #pragma unroll
             for (int nb = 0; nb < NA; ++nb) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[j] = *reinterpret_cast<const float *>(stage + (wave * NA + nb) * 4096 + 512 * ks + off[j]);
+                for (int jj = 0; jj < 8; ++jj)
+                    v[jj] = *reinterpret_cast<const float *>(stage + (wave * NA + nb) * 4096 + 512 * ks + off[jj]);
                 bsum[nb] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= gscale;
+                for (int jj = 0; jj < 8; ++jj) v[jj] *= gscale;
                 split8(v, ahi[nb], alo[nb]);
             }
+        };
+        float xr[8];
+        read_x(0, xr);
+        load_a(0);
+        h16x8 bhi, blo;
+        split8(xr, bhi, blo);
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                float v[8];
+        for (int st = 0; st < STEPS; ++st) {
+            const int kb = st % KB;
+            if (st + 1 < STEPS) read_x(st + 1, xr);
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[j] = *reinterpret_cast<const float *>(stage + A_BYTES + kb * 4096 + 512 * ks + off[j]);
-                h16x8 bhi, blo;
-                split8(v, bhi, blo);
+            for (int p = 0; p < PPS; ++p)
+                if (!FRONT && st * PPS + p < PER_WAVE) issue_piece(tn, nbuf, st * PPS + p);
+            unsigned H[4] = {0, 0, 0, 0}, L[4] = {0, 0, 0, 0};
+            auto pair = [&](int pp) {
+                if (st + 1 >= STEPS) return;
+                float r0, r1;
+                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(H[pp]) : "v"(xr[2 * pp]), "v"(xr[2 * pp + 1]));
+                asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(xr[2 * pp]), "v"(H[pp]));
+                asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(xr[2 * pp + 1]), "v"(H[pp]));
+                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(L[pp]) : "v"(r0), "v"(r1));
+            };
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int p = 0; p < PPS; ++p)
-                    if (!FRONT && (ks * KB + kb) * PPS + p < PER_WAVE) issue_piece(tn, nbuf, (ks * KB + kb) * PPS + p);
+            for (int m = 0; m < 3; ++m)
 #pragma unroll
                 for (int nb = 0; nb < NA; ++nb) {
-                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[nb], bhi, acc[nb][kb], 0, 0, 0);
-                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[nb], blo, acc[nb][kb], 0, 0, 0);
-                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[nb], bhi, acc[nb][kb], 0, 0, 0);
+                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(m == 0 ? alo[nb] : ahi[nb], m == 1 ? blo : bhi, acc[nb][kb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int idx = m * NA + nb;       // the pairs follow MFMA 1 .. : by then the reads above are back
+                    if (NA == 2 && idx >= 1 && idx <= 4) pair(idx - 1);
+                    if (NA == 1 && idx >= 1) { pair(2 * idx - 2); pair(2 * idx - 1); }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            if (st + 1 == KB) load_a(1);      // (the MFMAs above were the last to read the first k-step's dY fragments)
+            if (st + 1 < STEPS) {
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                const u4 hv = {H[0], H[1], H[2], H[3]}, lv = {L[0], L[1], L[2], L[3]};
+                bhi = __builtin_bit_cast(h16x8, hv);
+                blo = __builtin_bit_cast(h16x8, lv);
             }
         }
         buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
@@ -856,7 +889,9 @@ __device__ __forceinline__ float plane_scale(const unsigned *__restrict__ plane_
 }
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_x2_kernel(GemmTable table, float *__restrict__ partial, int64_t M,
-                                                                const unsigned *__restrict__ plane_max, ItemPlanes planes) {
+                                                                const unsigned *__restrict__ plane_max, ItemPlanes planes,
+                                                                unsigned long long *__restrict__ block_clocks) {
+    const unsigned long long clk0 = block_clocks ? wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -886,6 +921,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_x2_kernel(GemmTable table, 
         else dw_body_x2<1, 1>(g, slice, t0, t1, partial, lds, lane, wave, gscale);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (block_clocks && threadIdx.x == 0) block_clocks[blockIdx.x] = wall_clock64() - clk0;  // 100 MHz ticks
 }
 
 // the two thin rows the fp32 dW kernel sums as side jobs: fc_8.weight[0, :] = sum_m dsig[m] h7[m, :] and fc_out.weight[c, :] =
@@ -1071,7 +1107,12 @@ struct Plan {
     int64_t partial_floats;
 };
 
-Plan make_plan(const Net &net, int64_t M, int cus, const float *saved, const float *dy) {
+// mlp_bwd_dw_x2_kernel's relative time of one 32-row tile per item shape (scripts/dw_timing.py --f16x2, MI355X, all CUs
+// busy; same unit as the fp32 table in make_plan): its 256 x 256 tiles stream at 4.8 TB/s, so a tile's time follows its
+// BYTES (64 / 40 / 48 / 20 KiB), not its MFMAs -- planned with the fp32 kernel's costs the thin items' workgroups finished
+// at 5.7 ms, the wide ones' at 3.3 ms
+constexpr int X2_COST_256_256 = 7350, X2_COST_256_64 = 3207, X2_COST_128_256 = 6401, X2_COST_128_32 = 1927;
+Plan make_plan(const Net &net, int64_t M, int cus, const float *saved, const float *dy, bool x2 = false) {
     const int E_POS = net.e_pos, E_DIR = net.e_dir;
     const int64_t MP = padded_rows(M);
     const int64_t tiles = MP / 32;
@@ -1108,6 +1149,9 @@ Plan make_plan(const Net &net, int64_t M, int cus, const float *saved, const flo
         // finished 2.8 % after the mean and set the kernel's duration; density / fc_out items +0.4 %)
         T.g[k].cost = (T.g[k].flags & FLAG_DENSITY) ? 7480 : (T.g[k].flags & FLAG_FCOUT) ? 4145 : (aw == 256 && xw == 256) ? 7350
                     : (aw == 256 && xw == 64) ? 2010 : (aw == 128 && xw == 256) ? 3770 : 965;
+        // the split-f16 kernel: no side jobs, and a tile's time follows its bytes far more than its MFMAs (same units)
+        if (x2) T.g[k].cost = (aw == 256 && xw == 256) ? X2_COST_256_256 : (aw == 256 && xw == 64) ? X2_COST_256_64
+                            : (aw == 128 && xw == 256) ? X2_COST_128_256 : X2_COST_128_32;
         T.g[k].unit_off = units;
         units += tiles * T.g[k].cost;
     }
@@ -1356,6 +1400,26 @@ int launch_dx_f16x2(const void *packed_f16x2, int64_t M, const float *sigma, con
                     hipStream_t s);
 }
 
+// NERF_DW_TIMING=<file>: one line per workgroup -- first item it works on, its window, workgroup, clocks (100 MHz), the
+// item's planning cost; syncs
+static void dump_block_clocks(unsigned long long *clocks, const char *timing_path, const Plan &plan, hipStream_t s) {
+    if (!clocks) return;
+    std::vector<unsigned long long> host(plan.total_blocks);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(host.data(), clocks, sizeof(unsigned long long) * plan.total_blocks, hipMemcpyDeviceToHost);
+    (void)hipFree(clocks);
+    FILE *f = fopen(timing_path, "w");
+    if (!f) return;
+    for (int b = 0; b < plan.total_blocks; ++b) {
+        int item = 0;
+        for (int k = 0; k < plan.table.n; ++k)
+            if (b >= plan.table.g[k].first_block && b < plan.table.g[k].first_block + plan.table.g[k].num_slices) { item = k; break; }
+        fprintf(f, "%d %d %d %d %llu %lld\n", item, plan.table.g[item].a_width, plan.table.g[item].x_width, b, host[b],
+                (long long)plan.table.g[item].cost);
+    }
+    fclose(f);
+}
+
 // packed_f16x2 != NULL (and no input gradients asked for): stage 1, the reverse chain, runs on the split-f16 kernel; the
 // dW GEMMs run on the f16 pipe too (mlp_bwd_dw_x2_kernel: same items, work partition and partial-tile format), the two thin
 // side rows in a pass of their own, and the reduction takes the gradient planes' power-of-two scales out again
@@ -1389,14 +1453,14 @@ static int backward_impl(const nerf_net_t *net_abi, const void *packed, const vo
     float *dy = static_cast<float *>(workspace);
     float *partial = dy + align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE);
     const float *sv = static_cast<const float *>(saved);
-    const Plan plan = make_plan(net, M, cus, sv, dy);
+    const bool split = packed_f16x2 && !(g_pos || g_view_dir);
+    const Plan plan = make_plan(net, M, cus, sv, dy, split);
     float *bias_partial = partial + plan.partial_floats;
 
     const int64_t ntiles = MP / mlp::TILE_SAMPLES;
     const unsigned dx_grid = (unsigned)(ntiles < cus ? ntiles : (cus < 1024 ? cus : 1024));
     int bias_partials = (int)dx_grid * 4;
     int rc;
-    const bool split = packed_f16x2 && !input_grads;
     // (split path: 16 words of per-plane |dY| maxima + the thin rows' partial sums live behind the bias partials -- inside the
     // workspace: its partial-tile area is sized for 2 x 256 + 13 slices, a plan uses at most cus + 12)
     unsigned *plane_max = reinterpret_cast<unsigned *>(bias_partial + BIAS_PARTIAL_FLOATS);
@@ -1431,8 +1495,9 @@ static int backward_impl(const nerf_net_t *net_abi, const void *packed, const vo
         static const signed char item_plane[12] = {0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 9};     // make_plan's order
         for (int k = 0; k < tx.n; ++k) { tx.g[k].flags &= FLAG_BIAS; planes.p[k] = item_plane[k]; }
         hipLaunchKernelGGL(mlp_bwd_dw_x2_kernel, dim3((unsigned)plan.total_blocks), dim3(256), DW_LDS_BYTES, s, tx, partial, M,
-                           static_cast<const unsigned *>(plane_max), planes);
+                           static_cast<const unsigned *>(plane_max), planes, clocks);
         if ((rc = nerf::check_launch("nerf_mlp_backward_f16x2: dW")) != NERF_OK) return rc;
+        dump_block_clocks(clocks, timing_path, plan, s);
         int slices = (int)(MP / 32 / 8);
         slices = slices > X2_THIN_SLICES ? X2_THIN_SLICES : (slices < 1 ? 1 : slices);
         hipLaunchKernelGGL(fused_thin_kernel, dim3(12, slices), dim3(64), 0, s, sv, static_cast<const float *>(dy), MP, slices, thin_partial);
@@ -1447,21 +1512,7 @@ static int backward_impl(const nerf_net_t *net_abi, const void *packed, const vo
                        plan.table, sv, static_cast<const float *>(dy), partial, M, clocks);
     rc = nerf::check_launch("nerf_mlp_backward: dW");
     if (rc != NERF_OK) return rc;
-    if (clocks) {
-        std::vector<unsigned long long> host(plan.total_blocks);
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(host.data(), clocks, sizeof(unsigned long long) * plan.total_blocks, hipMemcpyDeviceToHost);
-        (void)hipFree(clocks);
-        if (FILE *f = fopen(timing_path, "w")) {   // one line per workgroup: first item it works on, clocks (100 MHz)
-            for (int b = 0; b < plan.total_blocks; ++b) {
-                int item = 0;
-                for (int k = 0; k < plan.table.n; ++k)
-                    if (b >= plan.table.g[k].first_block && b < plan.table.g[k].first_block + plan.table.g[k].num_slices) { item = k; break; }
-                fprintf(f, "%d %d %d %d %llu\n", item, plan.table.g[item].a_width, plan.table.g[item].x_width, b, host[b]);
-            }
-            fclose(f);
-        }
-    }
+    dump_block_clocks(clocks, timing_path, plan, s);
     hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(256, plan.table.n + 1), dim3(256), 0, s, plan.table,
                        static_cast<const float *>(partial), static_cast<const float *>(bias_partial), bias_partials,
                        g_params);
