@@ -153,9 +153,10 @@ int nerf_mlp_forward_f16x2(const nerf_net_t *net, const void *packed_f16x2, cons
  * reads: the forward third of a training step at the split kernel's rate, activations recorded to 2^-22.  Raw points. */
 int nerf_mlp_forward_f16x2_record(const nerf_net_t *net, const void *packed_f16x2, const float *pos, const float *view_dir,
                                   int64_t M, float *sigma, float *rgb, void *saved, nerf_stream_t stream);
-/* nerf_mlp_backward with its first stage -- the reverse chain dY(l-1) = W_l^T dY(l) -- on the split-f16 kernel (every
- * sample's gradient carries its own power-of-two scale through the chain: gradients are not O(1)); the dW GEMMs and the
- * reduction stay the fp32 kernels.  Parameter gradients only; same `saved`, `workspace` and g_params as nerf_mlp_backward. */
+/* nerf_mlp_backward on the split-f16 kernels: the reverse chain dY(l-1) = W_l^T dY(l) (every sample's gradient carries its
+ * own power-of-two scale through the chain: gradients are not O(1)) and the dW GEMMs dW_l = dY_l^T X_l (one power-of-two
+ * scale per gradient plane; fp32 accumulation, the fp32 path's partial tiles and fixed-order reduction).  Parameter
+ * gradients only; same `saved`, `workspace` and g_params as nerf_mlp_backward. */
 int nerf_mlp_backward_f16x2(const nerf_net_t *net, const void *packed, const void *packed_f16x2, int64_t M, const float *sigma,
                             const float *rgb, const void *saved, const float *g_sigma, const float *g_rgb, float *g_params,
                             void *workspace, nerf_stream_t stream);

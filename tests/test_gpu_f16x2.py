@@ -354,9 +354,9 @@ def test_record_forward_writes_the_fused_familys_record(oracle, M):
 @pytest.mark.parametrize("M", [1, 127, 1000, 20001])
 def test_reverse_chain_on_the_split_kernel(oracle, M):
     """nerf_mlp_backward_f16x2: stage 1 of the backward (dY(l-1) = W_l^T dY(l)) on the split-f16 kernel with a power-of-two
-    scale per sample, dW / reduction unchanged.  Gradients spanning eight decades between samples (upstream gradients
-    1e-6 .. 1e+2) must come out like the fp32 chain's: every element of every tensor against the oracle under the
-    record's ReLU decisions, and the gradient planes themselves against the fp32 chain's."""
+    scale per sample, stage 2 (dW_l = dY_l^T X_l) on it with ONE power-of-two scale per gradient plane, same partial tiles
+    and fixed-order reduction.  Gradients spanning eight decades between samples (upstream gradients 1e-6 .. 1e+2) must come
+    out like the fp32 kernels': every element of every tensor against the oracle under the record's ReLU decisions."""
     from helpers import assert_grads_match_given_masks, fused_masks
     rng = np.random.RandomState(M + 17)
     xs = rng.uniform(-3.0, 3.0, (M, 3)).astype(np.float32)
@@ -377,6 +377,30 @@ def test_reverse_chain_on_the_split_kernel(oracle, M):
     ref = oracle.mlp_backward_ex(flat, pe, de, gs, gc, want_inputs=False, force_masks=masks)[0]
     assert_grads_match_given_masks(got, ref, synth.split_flat_params, f"split dX, M={M} ")
     assert_grads_match_given_masks(ref32, ref, synth.split_flat_params, f"fp32 dX, M={M} ")
-    # twice: bit-identical (no atomics, fixed reduction order)
+    # twice: bit-identical (fixed reduction order; the only atomics are the planes' maxima, order-independent)
     again = ops.mlp_backward(p32, dev(flat), dev(xs), dev(vs), False, sx, cx, rec, dev(gs), dev(gc), packed_f16x2=px).cpu().numpy()
     assert np.array_equal(got, again)
+
+
+def test_split_backward_edge_gradients():
+    """The per-plane scale of the split dW GEMMs at its edges: no gradient at all (every plane's largest |dY| is zero: the
+    scale falls back to 1 and every weight gradient is exactly zero), one sample carrying all of it, and a non-finite
+    upstream gradient, which must come out non-finite -- never as a finite wrong number."""
+    M = 300
+    rng = np.random.RandomState(5)
+    xs = rng.uniform(-3.0, 3.0, (M, 3)).astype(np.float32)
+    vs = rng.uniform(-1.0, 1.0, (M, 3)).astype(np.float32)
+    flat = synth.nerf_flat_params(seed=4, sigma_bias=1.0, sigma_gain=30.0)
+    p32, px = ops.mlp_pack(dev(flat)), ops.mlp_pack_f16x2(dev(flat))
+    sx, cx, rec = ops.mlp_forward(p32, dev(xs), dev(vs), False, save=True)
+    run = lambda gs, gc, **kw: ops.mlp_backward(p32, dev(flat), dev(xs), dev(vs), False, sx, cx, rec, dev(gs), dev(gc), **kw).cpu().numpy()
+    zero = run(np.zeros(M, np.float32), np.zeros((M, 3), np.float32), packed_f16x2=px)
+    assert not zero.any()
+    gs, gc = np.zeros(M, np.float32), np.zeros((M, 3), np.float32)
+    gs[77], gc[77] = 3.0e-5, (1.0e-5, -2.0e-5, 4.0e-5)
+    one, one32 = run(gs, gc, packed_f16x2=px), run(gs, gc)
+    scale = np.abs(one32).max()
+    assert scale > 0 and np.abs(one - one32).max() <= 3e-6 * scale
+    gc[5, 1] = np.inf
+    bad = synth.split_flat_params(run(gs, gc, packed_f16x2=px))
+    assert not np.isfinite(bad["fc_out.weight"]).all() and not np.isfinite(bad["fc_in.weight"]).all()

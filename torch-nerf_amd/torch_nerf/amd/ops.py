@@ -431,8 +431,8 @@ def mlp_backward(packed, flat_params, pos, view_dir, encoded, sigma, rgb, saved,
                  net: Optional[Net] = None, want_pos: bool = False, want_dir: bool = False, packed_f16x2=None):
     """Parameter gradients as one flat tensor in state_dict order; with want_pos / want_dir -> (g_params, g_pos,
     g_view_dir): the gradients w.r.t. the ENCODED inputs, (M, pos_dim) / (M, view_dir_dim), None where not asked.
-    packed_f16x2 (a mlp_pack_f16x2 stream of the same parameters; parameter gradients only): the reverse chain runs on
-    the split-f16 kernel, the dW GEMMs stay fp32."""
+    packed_f16x2 (a mlp_pack_f16x2 stream of the same parameters; parameter gradients only): the reverse chain and the
+    dW GEMMs run on the split-f16 kernels (nerf_mlp_backward_f16x2)."""
     lib = _lib.load()
     M = pos.shape[0]
     g_sigma, g_rgb = _gpu(g_sigma, "g_sigma"), _gpu(g_rgb, "g_rgb")

@@ -56,10 +56,10 @@ class NeRF(nn.Module):
         # renders, run_render.py); the attribute can still be set per instance afterwards.
         self.f16x2_inference = os.environ.get("NERF_AMD_F16X2_INFERENCE", "0").lower() in ("1", "true", "on", "yes")
         self._packed_f16x2 = None
-        # Round 6, opt-in: run the RECORDING forward of a training step (raw points through the scene's fused query) and the
-        # reverse chain (dX) of its backward on the split-f16 kernels as well -- the same activation record and gradient
-        # planes (to 2^-22 instead of 2^-24; every sample's gradient carries its own power-of-two scale), the dW GEMMs stay
-        # the fp32 kernel: training step 25.8 -> 16.8 ms.  Fused family only.
+        # Round 6, opt-in: run the RECORDING forward of a training step (raw points through the scene's fused query), the
+        # reverse chain (dX) and the dW GEMMs of its backward on the split-f16 kernels as well -- the same activation record,
+        # gradient planes and partial tiles (to 2^-22 instead of 2^-24; every sample's gradient carries its own power-of-two
+        # scale through the chain, every gradient plane one through the GEMMs): training step 26.4 -> 12.4 ms.  Fused family only.
         self.f16x2_training = os.environ.get("NERF_AMD_F16X2_TRAINING", "0").lower() in ("1", "true", "on", "yes")
         self._flat_is_view = False
         self._rehome()
