@@ -727,10 +727,12 @@ __device__ __forceinline__ void dw_body_x2(const GemmDesc &g, int slice, int64_t
     constexpr int A_BYTES = 32 * AW * 4, X_BYTES = 32 * XW * 4, STAGE_BYTES = A_BYTES + X_BYTES;
     constexpr int NSTAGE = (KB <= 2) ? 3 : 2;
     // KB = 1 (the 128 x 32 direction item: six MFMAs per tile) issues the next tile's five pieces in one go behind the
-    // barrier.  Spread between the k-steps like the wider shapes, this one shape came back with wrong fc_9 direction columns
-    // on gfx950 -- the same wrong values with two and three stages and with a pause behind the barrier, right again with the
-    // pieces in front of or behind the k-steps; the ISA's addresses and waits check out and the cause was not found
-    // (scripts/diag_f16x2_dw.py is the check that caught it; tests/test_gpu_f16x2.py compares every tensor's entries).
+    // barrier.  With ALL five spread between the k-steps like the wider shapes' this one shape came back with wrong fc_9
+    // direction columns on gfx950 -- deterministically, the same wrong values with two and three stages, with vmcnt(0), with a
+    // pause behind the barrier and with the MFMAs drained by s_nops.  Right again: any ONE piece issued behind the last MFMAs
+    // instead (or all in front), and the five landing in an unused LDS region with the real ones issued behind; a compiler
+    // barrier or the M0 write alone at the same places change nothing.  The ISA's addresses, waits and operands check out line
+    // by line; the cause was not found (scripts/diag_f16x2_dw.py caught it; tests/test_gpu_f16x2.py compares every entry).
     constexpr bool FRONT = KB == 1;
     constexpr int PER_WAVE = A_PIECES + X_PIECES, SLOTS = 2 * KB, PPS = (PER_WAVE + SLOTS - 1) / SLOTS;
     static_assert(NSTAGE * STAGE_BYTES <= DW_LDS_BYTES, "stage ring exceeds the LDS allocation");
