@@ -160,6 +160,12 @@ int nerf_mlp_forward_f16x2_record(const nerf_net_t *net, const void *packed_f16x
 int nerf_mlp_backward_f16x2(const nerf_net_t *net, const void *packed, const void *packed_f16x2, int64_t M, const float *sigma,
                             const float *rgb, const void *saved, const float *g_sigma, const float *g_rgb, float *g_params,
                             void *workspace, nerf_stream_t stream);
+/* Host-only dry run of the bookkeeping of nerf_mlp_backward (f16x2 = 0) / nerf_mlp_backward_f16x2 (f16x2 = 1) on a device of
+ * `cus` compute units (<= 0: 256); nothing launched, no GPU needed: every item's 32-row tiles are covered exactly once by
+ * the workgroups the plan gives it, and the partial tiles, bias partials and (f16x2) plane maxima / thin-row partials fit the
+ * workspace nerf_mlp_backward_workspace_bytes sized.  NERF_OK, or NERF_ERR_ARG with the failed check in
+ * nerf_amd_last_error(). */
+int nerf_mlp_backward_plan_check(const nerf_net_t *net, int64_t M, int cus, int f16x2);
 
 /* ---- a13 (MLP part): gradients of all 22 parameter tensors (autograd in the
  * reference, entered at runners/train.py:215).  g_params (param_count floats, same

@@ -1396,6 +1396,63 @@ NERF_API int64_t nerf_mlp_backward_workspace_bytes(const nerf_net_t *net, int64_
     return 4 * (align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE) + partial + (int64_t)BIAS_PARTIAL_FLOATS);
 }
 
+// floats of the workspace behind the gradient planes that a launch touches: partial tiles, bias partials, and on the split
+// path the planes' maxima (16 words in a 64-float slot) and the thin rows' partial sums (doubles)
+static int64_t tail_floats_needed(const Plan &plan, bool split) {
+    return plan.partial_floats + BIAS_PARTIAL_FLOATS + (split ? 64 + 2 * (int64_t)X2_THIN_SLICES * 640 : 0);
+}
+
+NERF_API int nerf_mlp_backward_plan_check(const nerf_net_t *net_abi, int64_t M, int cus, int f16x2) {
+    mlp::Net net;
+    if (int rc = nerf::fused_net(net_abi, net, "nerf_mlp_backward_plan_check")) return rc;
+    NERF_REQUIRE(M >= 0 && M <= ((int64_t)1 << 31), "nerf_mlp_backward_plan_check: M out of range");
+    if (M == 0) return NERF_OK;
+    if (cus <= 0) cus = 256;
+    NERF_REQUIRE(!f16x2 || cus <= 384, "nerf_mlp_backward_plan_check: the split path's workspace layout assumes at most 384 compute units");
+    const int64_t MP = mlp::padded_rows(M), tiles = MP / 32;
+    const float *nowhere = reinterpret_cast<const float *>(uintptr_t(1) << 20);      // (the items' addresses are not looked at)
+    const Plan plan = make_plan(net, M, cus, nowhere, nowhere, f16x2 != 0);
+    const GemmTable &T = plan.table;
+    char why[200];
+    const int64_t B = plan.total_blocks;
+    NERF_REQUIRE(B >= 1 && B <= cus, "nerf_mlp_backward_plan_check: workgroup count outside [1, cus]");
+    int64_t partial = 0;
+    for (int k = 0; k < T.n; ++k) {
+        const GemmDesc &g = T.g[k];
+        int64_t next = 0;      // first tile not yet covered
+        for (int64_t b = 0; b < B; ++b) {
+            const int64_t lo = T.work_total * b / B, hi = T.work_total * (b + 1) / B;
+            auto tile_at = [&](int64_t unit) {
+                const int64_t rel = unit - g.unit_off;
+                const int64_t j = rel <= 0 ? 0 : (rel + g.cost - 1) / g.cost;
+                return j < tiles ? j : tiles;
+            };
+            const int64_t t0 = tile_at(lo), t1 = tile_at(hi);
+            const bool inside = b >= g.first_block && b < g.first_block + g.num_slices;
+            if (t0 < t1 && (!inside || t0 != next)) {
+                snprintf(why, sizeof why, "nerf_mlp_backward_plan_check: item %d, workgroup %lld: tiles [%lld, %lld) %s", k,
+                         (long long)b, (long long)t0, (long long)t1, inside ? "do not continue the previous workgroup's" : "outside the item's slices");
+                return nerf::fail(NERF_ERR_ARG, why);
+            }
+            if (t0 < t1) next = t1;
+        }
+        if (next != tiles) {
+            snprintf(why, sizeof why, "nerf_mlp_backward_plan_check: item %d: %lld of %lld tiles covered", k, (long long)next, (long long)tiles);
+            return nerf::fail(NERF_ERR_ARG, why);
+        }
+        NERF_REQUIRE(g.partial_off == partial, "nerf_mlp_backward_plan_check: partial tiles not packed back to back");
+        partial += (int64_t)g.num_slices * ((int64_t)g.a_width * g.x_width + SLICE_EXTRA);
+    }
+    NERF_REQUIRE(partial == plan.partial_floats, "nerf_mlp_backward_plan_check: partial_floats does not match the items");
+    const int64_t have = nerf_mlp_backward_workspace_bytes(net_abi, M) / 4 - align256f(MP * (int64_t)mlp::DY_FLOATS_PER_SAMPLE);
+    if (tail_floats_needed(plan, f16x2 != 0) > have) {
+        snprintf(why, sizeof why, "nerf_mlp_backward_plan_check: %lld floats behind the gradient planes, the workspace has %lld",
+                 (long long)tail_floats_needed(plan, f16x2 != 0), (long long)have);
+        return nerf::fail(NERF_ERR_ARG, why);
+    }
+    return NERF_OK;
+}
+
 namespace nerf {   // mlp_forward_f16x2.hip: stage 1 on the split-f16 kernel
 int launch_dx_f16x2(const void *packed_f16x2, int64_t M, const float *sigma, const float *rgb, const float *g_sigma,
                     const float *g_rgb, const float *saved, float *dy, float *bias_partial, int *partials, unsigned *plane_max,

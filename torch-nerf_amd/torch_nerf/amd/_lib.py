@@ -52,6 +52,7 @@ SIGNATURES = {
     "nerf_mlp_layered_workspace_bytes": (_c_i64, [_p, _c_i64]),
     "nerf_mlp_layered_plane": (_c_i64, [_p, _c_i64, _c_int, ctypes.POINTER(_c_int)]),
     "nerf_mlp_layered_plan_check": (_c_int, [_p, _c_i64, _c_int]),
+    "nerf_mlp_backward_plan_check": (_c_int, [_p, _c_i64, _c_int, _c_int]),
     "nerf_mlp_layered_forward": (_c_int, [_p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p, _c_i64, _c_int, _p]),
     "nerf_mlp_layered_backward": (_c_int, [_p, _p, _p, _p, _c_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_shenc": (_c_int, [_p, _c_i64, _c_int, _p, _p]),
