@@ -199,8 +199,19 @@ def train_leg(renderer, scene_c, scene_f, nets, pix, device, local_rank, steps, 
             net.f16x2_training = False
         fx = [a.elapsed_time(b) for tag, M, a, b in ev if tag == "mlp_forward"]
         bx = [a.elapsed_time(b) for tag, M, a, b in ev if tag == "mlp_backward"]
+        # what binds this step is HBM, not the matrix pipe: per sample the record goes out once (10 400 B) and comes back once
+        # (288 B of ReLU bits to the reverse chain, 10 112 B of activations to the dW GEMMs), the gradient planes likewise
+        # (9 748 B out of the reverse chain, 9 748 B into the GEMMs), 32 B of sigma / rgb and their gradients: DESIGN.md 4.8
+        x2_bytes = 10400 + 288 + 10112 + 2 * 9748 + 32
+        x2_samples = sum(M for tag, M, a, b in ev if tag == "mlp_forward")
+        x2_gbs = x2_samples * x2_bytes / ((sum(fx) + sum(bx)) * 1e-3) / 1e9
         split = {"ms_per_step": dtx / steps * 1e3, "rays_per_s": RAYS * steps / dtx, "speedup_vs_fp32_step": dt / dtx,
                  "forward_record_ms_per_step": round(sum(fx) / steps, 3), "backward_ms_per_step": round(sum(bx) / steps, 3),
+                 "roofline": {"bound": "hbm", "achieved": round(x2_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(x2_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                              "algorithmic_bytes_per_sample": x2_bytes,
+                              "kernel": "mlp_forward_f16x2_kernel<2,1,true> + mlp_bwd_dx_f16x2_kernel + mlp_bwd_dw_x2_kernel "
+                                        "(+ thin rows, reduction), HIP events around the forward and the backward of every launch"},
                  "what": "NeRF.f16x2_training: record forward, reverse chain (dX, one power-of-two scale per sample) and dW "
                          "GEMMs (one per gradient plane) on the split-f16 kernels; same record, gradient planes, partial "
                          "tiles and fixed-order reduction as the fp32 step, fp32 accumulation, fused Adam"}
