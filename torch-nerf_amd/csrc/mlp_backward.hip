@@ -680,10 +680,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(GemmTable table, con
 
 // the layered family's item list lives in device memory (header + items)
 __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_list_kernel(const GemmList *__restrict__ list,
-                                                                  float *__restrict__ partial, int64_t M) {
+                                                                  float *__restrict__ partial, int64_t M,
+                                                                  unsigned long long *__restrict__ block_clocks) {
+    const unsigned long long clk0 = block_clocks ? wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const GemmDesc *items = reinterpret_cast<const GemmDesc *>(list + 1);
     dw_main<true>(items, list->n, list->work_total, nullptr, nullptr, partial, M, lds, list->side_h9 ? list : nullptr);
+    if (block_clocks && threadIdx.x == 0) block_clocks[blockIdx.x] = wall_clock64() - clk0;  // 100 MHz ticks
 }
 
 
@@ -1300,8 +1303,12 @@ static void plan_dw_items(const std::vector<DwItem> &items, int64_t M, int cus, 
         g.w_off = it.w_dst - P.base; g.b_off = it.b_dst ? it.b_dst - P.base : 0;
         // relative tile times by shape (measured for the fused family's four shapes, mlp_backward.hip:make_plan)
         const int nk = NA * KB;
-        g.cost = (it.side & FLAG_DENSITY) ? 7480 : (it.side & FLAG_FCOUT) ? 4145
-                 : nk == 16 ? 7350 : (NA == 1 && KB == 8) ? 3770 : (NA == 2 && KB == 2) ? 2010 : nk == 1 ? 935 : 450 * nk + 150;
+        // (round 6, scripts/dw_list_timing.py on NeRF(75, 27, 256) and NeRF(63, 33, 256): the 256 x 96 window 2850 -> 2900, the
+        // 128 x 32 one 935 -> 960, the 128 x 64 one 1050 -> 1120, the fc_out side job 4145 -> 4165 -- the three workgroups of
+        // the thin direction item finished 4 % / 7 % behind the mean and set the kernel's duration)
+        g.cost = (it.side & FLAG_DENSITY) ? 7480 : (it.side & FLAG_FCOUT) ? 4165
+                 : nk == 16 ? 7350 : (NA == 1 && KB == 8) ? 3770 : (NA == 2 && KB == 2) ? 2010 : nk == 1 ? 960
+                 : (NA == 2 && KB == 3) ? 2900 : (NA == 1 && KB == 2) ? 1120 : 450 * nk + 150;
         if (g.a_split > 1) {   // MFMA time of a wave's share, or the tile's bytes at the CU's share of HBM (~11 B / clock)
             const int mfma = 450 * KB / g.a_split + 150, hbm = 5 * (128 / g.a_split + 32 * KB);
             g.cost = mfma > hbm ? mfma : hbm;
@@ -1378,8 +1385,28 @@ int run_dw_items(const std::vector<DwItem> &items, int64_t M, void *scratch, int
     ring.mark(slot, s);
     const GemmList *list = static_cast<const GemmList *>(scratch);
     float *partial = reinterpret_cast<float *>(static_cast<char *>(scratch) + P.list_bytes);
-    hipLaunchKernelGGL(mlp_bwd_dw_list_kernel, dim3((unsigned)P.B), dim3(256), DW_LDS_BYTES, s, list, partial, M);
+    // NERF_DW_TIMING=<file>: debugging aid, dumps per-workgroup durations of the dW kernel (syncs!), as for the fused family
+    const char *timing_path = getenv("NERF_DW_TIMING");
+    unsigned long long *clocks = nullptr;
+    if (timing_path && hipMalloc(&clocks, sizeof(unsigned long long) * P.B) != hipSuccess) clocks = nullptr;
+    hipLaunchKernelGGL(mlp_bwd_dw_list_kernel, dim3((unsigned)P.B), dim3(256), DW_LDS_BYTES, s, list, partial, M, clocks);
     if (int rc = nerf::check_launch("nerf_mlp_layered_backward: dW")) return rc;
+    if (clocks) {
+        std::vector<unsigned long long> host(P.B);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(host.data(), clocks, sizeof(unsigned long long) * P.B, hipMemcpyDeviceToHost);
+        (void)hipFree(clocks);
+        if (FILE *f = fopen(timing_path, "w")) {
+            for (int64_t b = 0; b < P.B; ++b) {
+                int item = 0;
+                for (int k = 0; k < n; ++k)
+                    if (b >= P.G[k].first_block && b < P.G[k].first_block + P.G[k].num_slices) { item = k; break; }
+                fprintf(f, "%d %d %d %lld %llu %lld %d\n", item, P.G[item].a_width, P.G[item].x_width, (long long)b, host[b],
+                        (long long)P.G[item].cost, P.G[item].flags);
+            }
+            fclose(f);
+        }
+    }
     hipLaunchKernelGGL(mlp_bwd_reduce_list_kernel, dim3(64, n), dim3(256), 0, s, list,
                        static_cast<const float *>(partial), P.base);
     return nerf::check_launch("nerf_mlp_layered_backward: reduce");
