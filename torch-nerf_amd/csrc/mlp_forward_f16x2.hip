@@ -188,10 +188,11 @@ struct Recorder {
         char *p = base + 4 * (plane + tile32 * 32 * width) + (fb >> 1) * 4096 + ((fb & 1) ? off_odd : off_even);
         // Nontemporal: these planes are read next by ANOTHER kernel, 8 GB of stores later -- kept out of the L2's way they cost
         // 2 % less (record forward 2.69 -> 2.63 ms, reverse chain alike; sc1 loses 5 %).  Without any store the record
-        // forward takes 2.12 ms: their price is not instruction issue (162 of them per 3476 MFMAs) and not the HBM's store rate
-        // (scripts/hbm_write_probe.hip: 6.3 TB/s for this pattern); their share of the in-order vmcnt waits and the power the
-        // traffic takes from a power-bound kernel were not separated.  (s_nop 1: two wait states before anything may
-        // overwrite the data registers.)
+        // forward takes 2.12 ms, and with the same stores aimed at 1 MiB that stays in the L2 (no HBM traffic) 2.54: four
+        // fifths of their price is on the chip -- 1 KiB per instruction through the CU's 64 B / clock store path, in the
+        // layer seams where the matrix pipe idles anyway, and their share of the in-order vmcnt waits -- not the HBM
+        // (scripts/hbm_write_probe.hip: 6.3 TB/s for this pattern).  (s_nop 1: two wait states before anything may overwrite
+        // the data registers.)
         asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
         ++pipe.stores;
     }
