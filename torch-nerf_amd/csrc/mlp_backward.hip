@@ -793,10 +793,11 @@ __device__ __forceinline__ void dw_body_x2(const GemmDesc &g, int slice, int64_t
 #pragma unroll
             for (int j = 0; j < PER_WAVE; ++j) issue_piece(tn, nbuf, j);
         }
-        // Two k-steps x KB column blocks = 2 KB steps, software-pipelined by hand: step s issues the LDS reads of step
-        // s + 1's X fragment first, then its own MFMAs, and splits that fragment in their shadow (a pair of samples = four
-        // vector instructions between two MFMAs; sched_barrier pins the order -- left to itself the compiler splits first and
-        // the matrix pipe waits out every LDS round trip: 12.4 k clocks per 256 x 256 tile instead of ~4 k).
+        // Two k-steps x KB column blocks = 2 KB steps, software-pipelined by hand: step s requests the X fragment of step
+        // s + 2, issues its own MFMAs and splits step s + 1's fragment in their shadow (a pair of samples = four vector
+        // instructions behind each MFMA; sched_barrier pins the order -- left to itself the compiler reads, splits and only
+        // then multiplies, and the matrix pipe waits out every LDS round trip: 12.4 k clocks per 256 x 256 tile; one step
+        // ahead 6.3 k, two steps ahead 5.6 k; the pipe needs 3.1 k, the tile's DMA round trip 4.8 k).
         constexpr int STEPS = 2 * KB;
         auto read_x = [&](int st, float (&r)[8]) {
             const int ks = st / KB, kb = st % KB;
@@ -805,40 +806,53 @@ __device__ __forceinline__ void dw_body_x2(const GemmDesc &g, int slice, int64_t
                 r[jj] = *reinterpret_cast<const float *>(stage + A_BYTES + kb * 4096 + 512 * ks + off[jj]);
         };
         h16x8 ahi[NA], alo[NA];
-        auto load_a = [&](int ks) {
+        float ar[NA][8];                      // raw dY fragments of the second k-step, read at the top of the tile
+        auto read_a = [&](int ks) {
+#pragma unroll
+            for (int nb = 0; nb < NA; ++nb)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    ar[nb][jj] = *reinterpret_cast<const float *>(stage + (wave * NA + nb) * 4096 + 512 * ks + off[jj]);
+        };
+        auto split_a = [&]() {
 #pragma unroll
             for (int nb = 0; nb < NA; ++nb) {
                 float v[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj)
-                    v[jj] = *reinterpret_cast<const float *>(stage + (wave * NA + nb) * 4096 + 512 * ks + off[jj]);
+                for (int jj = 0; jj < 8; ++jj) v[jj] = ar[nb][jj];
                 bsum[nb] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) v[jj] *= gscale;
                 split8(v, ahi[nb], alo[nb]);
             }
         };
-        float xr[8];
-        read_x(0, xr);
-        load_a(0);
+        // X fragments are read TWO steps ahead (a read issued one step ahead comes back ~100 clocks after the MFMAs that
+        // should hide it have drained: 6.3 k clocks per 256 x 256 tile; the matrix pipe needs 3.1 k)
+        float xr[2][8];
+        read_x(0, xr[0]);
+        read_a(0);
+        if (STEPS > 1) read_x(1, xr[1]);
+        split_a();
+        read_a(1);
         h16x8 bhi, blo;
-        split8(xr, bhi, blo);
+        split8(xr[0], bhi, blo);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
             const int kb = st % KB;
-            if (st + 1 < STEPS) read_x(st + 1, xr);
-#pragma unroll
-            for (int p = 0; p < PPS; ++p)
-                if (!FRONT && st * PPS + p < PER_WAVE) issue_piece(tn, nbuf, st * PPS + p);
+            const float (&cur)[8] = xr[(st + 1) & 1];       // step st + 1's fragment, requested at the top of step st - 1
+            if (st + 2 < STEPS) read_x(st + 2, xr[st & 1]);  // (step st's own was split during step st - 1: its registers are free)
             unsigned H[4] = {0, 0, 0, 0}, L[4] = {0, 0, 0, 0};
             auto pair = [&](int pp) {
                 if (st + 1 >= STEPS) return;
                 float r0, r1;
-                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(H[pp]) : "v"(xr[2 * pp]), "v"(xr[2 * pp + 1]));
-                asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(xr[2 * pp]), "v"(H[pp]));
-                asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(xr[2 * pp + 1]), "v"(H[pp]));
+                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(H[pp]) : "v"(cur[2 * pp]), "v"(cur[2 * pp + 1]));
+                asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(cur[2 * pp]), "v"(H[pp]));
+                asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(cur[2 * pp + 1]), "v"(H[pp]));
                 asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(L[pp]) : "v"(r0), "v"(r1));
             };
+#pragma unroll
+            for (int p = 0; p < PPS; ++p)
+                if (!FRONT && st * PPS + p < PER_WAVE) issue_piece(tn, nbuf, st * PPS + p);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < 3; ++m)
@@ -846,12 +860,12 @@ __device__ __forceinline__ void dw_body_x2(const GemmDesc &g, int slice, int64_t
                 for (int nb = 0; nb < NA; ++nb) {
                     acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(m == 0 ? alo[nb] : ahi[nb], m == 1 ? blo : bhi, acc[nb][kb], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int idx = m * NA + nb;       // the pairs follow MFMA 1 .. : by then the reads above are back
-                    if (NA == 2 && idx >= 1 && idx <= 4) pair(idx - 1);
-                    if (NA == 1 && idx >= 1) { pair(2 * idx - 2); pair(2 * idx - 1); }
+                    const int idx = m * NA + nb;       // a pair of samples (four vector instructions) behind each MFMA
+                    if (NA == 2 && idx <= 3) pair(idx);
+                    if (NA == 1 && idx <= 1) { pair(2 * idx); pair(2 * idx + 1); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            if (st + 1 == KB) load_a(1);      // (the MFMAs above were the last to read the first k-step's dY fragments)
+            if (st + 1 == KB) split_a();      // (the MFMAs above were the last to read the first k-step's dY fragments)
             if (st + 1 < STEPS) {
                 typedef unsigned u4 __attribute__((ext_vector_type(4)));
                 const u4 hv = {H[0], H[1], H[2], H[3]}, lv = {L[0], L[1], L[2], L[3]};
@@ -932,18 +946,22 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dw_x2_kernel(GemmTable table, 
 // the two thin rows the fp32 dW kernel sums as side jobs: fc_8.weight[0, :] = sum_m dsig[m] h7[m, :] and fc_out.weight[c, :] =
 // sum_m gy[m][c] h9[m, :] -- one pass over the h7 / h9 planes of the record (HBM-bound), double accumulation, fixed order
 constexpr int X2_THIN_SLICES = 512;
+// H7: blocks 0..7 of the h7 plane against dsig (16 double accumulators per lane); otherwise blocks 0..3 of the h9 plane against
+// the three colour gradients (48).  Two instances instead of one kernel that carries the larger accumulator set for both: the
+// common one needed 258 registers = ONE wavefront per SIMD, and a loop of dependent 2 us round trips at that occupancy took
+// 450 us for 1.2 GB.
+template <bool H7>
 __global__ __launch_bounds__(64) void fused_thin_kernel(const float *__restrict__ saved, const float *__restrict__ dy, int64_t MP,
                                                         int slices, double *__restrict__ partial) {
-    const int blk = blockIdx.x, lane = threadIdx.x, i = lane & 31, h = lane >> 5;
-    const bool is_h7 = blk < 8;
-    const int fb = is_h7 ? blk : blk - 8, width = is_h7 ? 256 : 128;
-    const float *plane = saved + (is_h7 ? pl_h(MP, 7) : pl_h9(MP));
+    constexpr int NC = H7 ? 1 : 3, width = H7 ? 256 : 128;
+    const int fb = blockIdx.x, lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const float *plane = saved + (H7 ? pl_h(MP, 7) : pl_h9(MP));
     const float *gy = dy + gy_plane(MP), *ds = dy + dsig_plane(MP);
     const int64_t tiles = MP / 32, per = (tiles + slices - 1) / slices;
     const int64_t t0 = blockIdx.y * per, t1 = t0 + per < tiles ? t0 + per : tiles;
-    double acc[3][16];
+    double acc[NC][16];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0;
     for (int64_t t = t0; t < t1; ++t) {
@@ -955,7 +973,7 @@ __global__ __launch_bounds__(64) void fused_thin_kernel(const float *__restrict_
             const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + qq * 256 + 4 * ((2 * i + h) ^ (2 * qq)));
             x[4 * qq] = v.x; x[4 * qq + 1] = v.y; x[4 * qq + 2] = v.z; x[4 * qq + 3] = v.w;
         }
-        if (is_h7) {
+        if (H7) {
             const double gd = (double)ds[m];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] += gd * (double)x[r];
@@ -964,22 +982,21 @@ __global__ __launch_bounds__(64) void fused_thin_kernel(const float *__restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[0][r] += (double)g4.x * (double)x[r];
-                acc[1][r] += (double)g4.y * (double)x[r];
-                acc[2][r] += (double)g4.z * (double)x[r];
+                acc[NC > 1 ? 1 : 0][r] += (double)g4.y * (double)x[r];
+                acc[NC > 2 ? 2 : 0][r] += (double)g4.z * (double)x[r];
             }
         }
     }
     double *out = partial + (int64_t)blockIdx.y * (256 + 3 * 128);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (is_h7 && c > 0) break;
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             double v = acc[c][r];
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);      // over the 32 samples of this lane half
             const int k = 32 * fb + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (i == 0) out[is_h7 ? k : 256 + c * 128 + k] = v;
+            if (i == 0) out[H7 ? k : 256 + c * 128 + k] = v;
         }
     }
 }
@@ -1113,10 +1130,10 @@ struct Plan {
 };
 
 // mlp_bwd_dw_x2_kernel's relative time of one 32-row tile per item shape (scripts/dw_timing.py --f16x2, MI355X, all CUs
-// busy; same unit as the fp32 table in make_plan): its 256 x 256 tiles stream at 4.8 TB/s, so a tile's time follows its
-// BYTES (64 / 40 / 48 / 20 KiB), not its MFMAs -- planned with the fp32 kernel's costs the thin items' workgroups finished
-// at 5.7 ms, the wide ones' at 3.3 ms
-constexpr int X2_COST_256_256 = 7350, X2_COST_256_64 = 3207, X2_COST_128_256 = 6401, X2_COST_128_32 = 1927;
+// busy; same unit as the fp32 table in make_plan): its 256 x 256 tiles stream at 4.9 TB/s, so a tile's time follows its
+// BYTES (64 / 40 / 48 / 20 KiB) far more than its MFMAs -- planned with the fp32 kernel's costs the thin items' workgroups
+// finished at 5.7 ms, the wide ones' at 3.3 ms
+constexpr int X2_COST_256_256 = 7350, X2_COST_256_64 = 3207, X2_COST_128_256 = 5120, X2_COST_128_32 = 1865;
 Plan make_plan(const Net &net, int64_t M, int cus, const float *saved, const float *dy, bool x2 = false) {
     const int E_POS = net.e_pos, E_DIR = net.e_dir;
     const int64_t MP = padded_rows(M);
@@ -1586,7 +1603,8 @@ static int backward_impl(const nerf_net_t *net_abi, const void *packed, const vo
         dump_block_clocks(clocks, timing_path, plan, s);
         int slices = (int)(MP / 32 / 8);
         slices = slices > X2_THIN_SLICES ? X2_THIN_SLICES : (slices < 1 ? 1 : slices);
-        hipLaunchKernelGGL(fused_thin_kernel, dim3(12, slices), dim3(64), 0, s, sv, static_cast<const float *>(dy), MP, slices, thin_partial);
+        hipLaunchKernelGGL(fused_thin_kernel<true>, dim3(8, slices), dim3(64), 0, s, sv, static_cast<const float *>(dy), MP, slices, thin_partial);
+        hipLaunchKernelGGL(fused_thin_kernel<false>, dim3(4, slices), dim3(64), 0, s, sv, static_cast<const float *>(dy), MP, slices, thin_partial);
         hipLaunchKernelGGL(mlp_bwd_reduce_x2_kernel, dim3(256, tx.n + 1), dim3(256), 0, s, tx,
                            static_cast<const float *>(partial), static_cast<const float *>(bias_partial), bias_partials, g_params,
                            static_cast<const unsigned *>(plane_max), planes);
