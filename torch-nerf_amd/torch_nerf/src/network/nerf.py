@@ -59,7 +59,7 @@ class NeRF(nn.Module):
         # Round 6, opt-in: run the RECORDING forward of a training step (raw points through the scene's fused query), the
         # reverse chain (dX) and the dW GEMMs of its backward on the split-f16 kernels as well -- the same activation record,
         # gradient planes and partial tiles (to 2^-22 instead of 2^-24; every sample's gradient carries its own power-of-two
-        # scale through the chain, every gradient plane one through the GEMMs): training step 26.4 -> 12.4 ms.  Fused family only.
+        # scale through the chain, every gradient plane one through the GEMMs): training step 25.9 -> 11.5 ms.  Fused family only.
         self.f16x2_training = os.environ.get("NERF_AMD_F16X2_TRAINING", "0").lower() in ("1", "true", "on", "yes")
         self._flat_is_view = False
         self._rehome()
