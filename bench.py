@@ -727,9 +727,24 @@ def runner_loop_leg(device, local_rank, steps, warmup):
         step(k, True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the same unmodified loop with NERF_AMD_F16X2_TRAINING=1's effect: every network's training step on the split-f16 kernels
+    for net in nets:
+        net.f16x2_training = True
+    for k in range(2):
+        step(k, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(warmup, warmup + steps):
+        step(k, False)
+    torch.cuda.synchronize()
+    dtx = time.perf_counter() - t0
+    for net in nets:
+        net.f16x2_training = False
     torch.set_num_threads(threads_before)
     return {"ms_per_step": dt / steps * 1e3, "rays_per_s": RAYS * steps / dt, "steps": steps,
             "torch_num_threads": 1,
+            "f16x2_training": {"ms_per_step": dtx / steps * 1e3, "rays_per_s": RAYS * steps / dtx,
+                               "what": "the same loop with NERF_AMD_F16X2_TRAINING=1 (NeRF.f16x2_training on both networks)"},
             "host_ms_per_step": {k: round(v / steps * 1e3, 3) for k, v in clock.items()},
             "np_random_choice_ms": round(choice_ms, 3),
             "what": "runners/train.py:120-218 verbatim against the drop-in classes: camera per batch, np.random.choice "
