@@ -735,7 +735,8 @@ __device__ __forceinline__ void dw_body_x2(const GemmDesc &g, int slice, int64_t
     // pause behind the barrier and with the MFMAs drained by s_nops.  Right again: any ONE piece issued behind the last MFMAs
     // instead (or all in front), and the five landing in an unused LDS region with the real ones issued behind; a compiler
     // barrier or the M0 write alone at the same places change nothing; one tile per workgroup (the pieces then land in a stage
-    // nobody reads) fails the same way.  The ISA's addresses, waits and operands check out line by line; the cause was not found (scripts/diag_f16x2_dw.py caught it; tests/test_gpu_f16x2.py compares every entry).
+    // nobody reads) fails the same way; with every LDS read of the tile waited for before the first piece it is right: the ds_reads
+    // behind the pieces are what comes back wrong.  The ISA's addresses, waits and operands check out line by line; why was not found (scripts/diag_f16x2_dw.py caught it; tests/test_gpu_f16x2.py compares every entry).
     constexpr bool FRONT = KB == 1;
     constexpr int PER_WAVE = A_PIECES + X_PIECES, SLOTS = 2 * KB, PPS = (PER_WAVE + SLOTS - 1) / SLOTS;
     static_assert(NSTAGE * STAGE_BYTES <= DW_LDS_BYTES, "stage ring exceeds the LDS allocation");
